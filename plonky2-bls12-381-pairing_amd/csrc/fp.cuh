@@ -1,0 +1,460 @@
+// Fp layer of the MI355X pairing engine: GF(p) for the BLS12-381 base field on gfx950.
+//
+// Replaces (behind the C ABI in include/bls381_hip.h) the Fp arithmetic that the reference takes
+// from ark-ff `Fq` [third party] and restates in src/fields/bls12_381base.rs:174-268.
+//
+// Representation (chosen from the instruction-rate measurements in profiles/r01_valu_rates_mi355x.txt:
+// on gfx950 a carry-writing add costs as much as a 32x32+64 multiply-add, so carries are designed out):
+//   * 14 limbs x 28 bits in 32-bit registers ("U28"), value = sum l[i] << 28 i.  Limbs may exceed 28 bits
+//     between multiplications (additions never propagate carries).
+//   * Montgomery form with R = 2^392: 11 bits above p, so products of unreduced operands (values up to
+//     tens of p) still reduce to < 2p with no conditional subtraction anywhere on the hot path.
+//   * One multiplication = finely-integrated product scanning: every column is a chain of
+//     v_mad_u64_u32 into one 64-bit accumulator that cannot overflow (bounds below), then one
+//     v_mul_lo/v_and (Montgomery quotient digit) and one 64-bit shift.  No carry flag is ever used.
+//   * `mont2` accumulates TWO products before the single reduction (a*b + c*d): an Fp2 multiplication
+//     is two of those -- schoolbook with lazy reduction -- with no Karatsuba pre/post additions.
+//
+// Bounds are part of the type: Fp<L, V> promises  limb < L * 2^28 (+ a few units)  and  value < V * p.
+// Every operation static_asserts that its accumulators cannot overflow, so an unsafe lazy-reduction
+// chain is a compile error, not a wrong answer.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BLS_HD __host__ __device__ __forceinline__
+#define BLS_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define BLS_HD inline __attribute__((always_inline))
+#define BLS_HD_NOINLINE __attribute__((noinline))
+#endif
+#define BLS_CONST static constexpr
+
+#include "fp_consts.h"
+
+namespace bls {
+
+constexpr int NL = 14;                 // limbs
+constexpr int LW = 28;                 // limb width
+constexpr uint32_t LMASK = (1u << LW) - 1u;
+
+// Limit for the product terms of one accumulator column:
+//   14 * (sum of La*Lb over the fused products) * 2^56  +  14 * 2^56 (m * p)  +  carry-in (< 2^37)  <  2^64
+// <=> sum(La*Lb) + 1 <= 18 (252/256 used; the slack covers the "+ few units" of almost-normalised limbs).
+constexpr int MONT_LL_MAX = 17;
+// Value bounds carry 1% slack: "V" promises value < V * 1.01 p.  A product of bounds Va, Vb reduces to
+//   < ((sum Va*Vb) * 1.01^2 * p / 2^392 + 1) p   with  p / 2^392 < 1 / 2520.3,
+// which stays < 2.02 p (i.e. V = 2) while sum(Va*Vb) <= 2500.  The slack absorbs the quotient estimate of
+// weak_reduce() below.
+constexpr int MONT_VV_MAX = 2500;
+
+#ifdef BLS_BOUND_CHECK
+// Host-only instrumentation (tests/hostsim): verifies at run time that the compile-time bounds hold.
+void bound_check_fail(const char* what);
+void bound_check(const uint32_t* l, int L, int V);
+#endif
+
+template <int L, int V>
+struct Fp {
+  static constexpr int kL = L, kV = V;
+  uint32_t l[NL];
+
+  // widening conversion: a tighter bound is always a valid looser bound
+  template <int L2, int V2>
+  BLS_HD Fp(const Fp<L2, V2>& o) {
+    static_assert(L2 <= L && V2 <= V, "cannot narrow Fp bounds implicitly");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) l[i] = o.l[i];
+  }
+  Fp() = default;
+  BLS_HD void chk() const {
+#ifdef BLS_BOUND_CHECK
+    bound_check(l, L, V);
+#endif
+  }
+};
+
+using FpR = Fp<1, 2>;   // "reduced": what every Montgomery multiplication returns
+
+// ------------------------------------------------------------------------------------------------
+// Montgomery multiplication core on raw limb arrays.  N_PROD = 1: a*b ; N_PROD = 2: a*b + c*d.
+// Fully unrolled: 196 MADs per product + 196 for the reduction.
+template <int N_PROD>
+BLS_HD void mont_core(uint32_t* __restrict__ out, const uint32_t* a, const uint32_t* b,
+                      const uint32_t* c, const uint32_t* d) {
+  uint32_t m[NL];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      acc += (uint64_t)a[i] * b[k - i];
+      if (N_PROD == 2) acc += (uint64_t)c[i] * d[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * BLS_P28[k - i];
+    m[k] = ((uint32_t)acc * BLS_PINV28) & LMASK;
+    acc += (uint64_t)m[k] * BLS_P28[0];
+    acc >>= LW;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) {
+      acc += (uint64_t)a[i] * b[k - i];
+      if (N_PROD == 2) acc += (uint64_t)c[i] * d[k - i];
+    }
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * BLS_P28[k - i];
+    out[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LW;
+  }
+  out[NL - 1] = (uint32_t)acc;
+}
+
+// Montgomery squaring core: a*a with the cross terms doubled (105 + 196 MADs instead of 392).
+BLS_HD void mont_sqr_core(uint32_t* __restrict__ out, const uint32_t* a) {
+  uint32_t m[NL], a2[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) a2[i] = a[i] << 1;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; ++k) {
+    const int lo = (k < NL) ? 0 : k - NL + 1;
+    const int hi = (k < NL) ? k : NL - 1;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      const int j = k - i;
+      if (i < j) acc += (uint64_t)a2[i] * a[j];
+      else if (i == j) acc += (uint64_t)a[i] * a[i];
+    }
+    if (k < NL) {
+#pragma unroll
+      for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * BLS_P28[k - i];
+      m[k] = ((uint32_t)acc * BLS_PINV28) & LMASK;
+      acc += (uint64_t)m[k] * BLS_P28[0];
+    } else {
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * BLS_P28[k - i];
+      out[k - NL] = (uint32_t)acc & LMASK;
+    }
+    acc >>= LW;
+  }
+  out[NL - 1] = (uint32_t)acc;
+}
+
+#ifndef BLS_MONT_INLINE
+#define BLS_MONT_INLINE 1
+#endif
+#if BLS_MONT_INLINE
+#define BLS_MONT_FN BLS_HD
+#else
+#define BLS_MONT_FN BLS_HD_NOINLINE
+#endif
+
+struct Raw { uint32_t l[NL]; };
+BLS_MONT_FN Raw mont1_raw(Raw a, Raw b) { Raw r; mont_core<1>(r.l, a.l, b.l, nullptr, nullptr); return r; }
+BLS_MONT_FN Raw mont2_raw(Raw a, Raw b, Raw c, Raw d) { Raw r; mont_core<2>(r.l, a.l, b.l, c.l, d.l); return r; }
+BLS_MONT_FN Raw montsqr_raw(Raw a) { Raw r; mont_sqr_core(r.l, a.l); return r; }
+
+template <int L, int V> BLS_HD Raw raw_of(const Fp<L, V>& a) { Raw r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  return r; }
+BLS_HD FpR fp_of(const Raw& a) { FpR r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  return r; }
+
+// a * b / R  (mod p), result < 2p, limbs normalised
+template <int La, int Va, int Lb, int Vb>
+BLS_HD FpR mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+  static_assert(La * Lb <= MONT_LL_MAX, "mul: limb bounds overflow the 64-bit column accumulator");
+  static_assert(Va * Vb <= MONT_VV_MAX, "mul: value bounds break the < 2p result guarantee");
+  FpR r = fp_of(mont1_raw(raw_of(a), raw_of(b)));
+  r.chk();
+  return r;
+}
+
+template <int La, int Va>
+BLS_HD FpR sqr(const Fp<La, Va>& a) {
+  // doubled operand: 2a has limb bound 2 La; cross products 2a_i * a_j
+  static_assert(2 * La * La <= MONT_LL_MAX * 2, "sqr: limb bounds overflow");   // same column total as a*a
+  static_assert(La * La <= MONT_LL_MAX, "sqr: limb bounds overflow");
+  static_assert(Va * Va <= MONT_VV_MAX, "sqr: value bounds");
+  FpR r = fp_of(montsqr_raw(raw_of(a)));
+  r.chk();
+  return r;
+}
+
+// (a*b + c*d) / R  (mod p), result < 2p -- one reduction for two products
+template <int La, int Va, int Lb, int Vb, int Lc, int Vc, int Ld, int Vd>
+BLS_HD FpR mul2(const Fp<La, Va>& a, const Fp<Lb, Vb>& b, const Fp<Lc, Vc>& c, const Fp<Ld, Vd>& d) {
+  static_assert(La * Lb + Lc * Ld <= MONT_LL_MAX, "mul2: limb bounds overflow the 64-bit column accumulator");
+  static_assert(Va * Vb + Vc * Vd <= MONT_VV_MAX, "mul2: value bounds break the < 2p result guarantee");
+  FpR r = fp_of(mont2_raw(raw_of(a), raw_of(b), raw_of(c), raw_of(d)));
+  r.chk();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// additions: limb-wise, no carries.  When the result would leave the representable bounds (limb < 15 * 2^28,
+// value < 64 * 1.01 p) the larger operand is conditioned first (norm / weak_reduce), decided at compile time.
+constexpr int L_CAP = 15;
+constexpr int V_CAP = 64;
+
+template <int L, int V> BLS_HD Fp<1, V> norm(const Fp<L, V>& a);
+template <int L, int V> BLS_HD Fp<1, 2> weak_reduce(const Fp<L, V>& a);
+
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto add(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+  if constexpr (Va + Vb > V_CAP) {
+    if constexpr (Va >= Vb) return add(weak_reduce(a), b); else return add(a, weak_reduce(b));
+  } else if constexpr (La + Lb > L_CAP) {
+    if constexpr (La >= Lb) return add(norm(a), b); else return add(a, norm(b));
+  } else {
+    Fp<La + Lb, Va + Vb> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+    r.chk();
+    return r;
+  }
+}
+
+template <int La, int Va>
+BLS_HD auto dbl(const Fp<La, Va>& a) {
+  if constexpr (2 * Va > V_CAP) return dbl(weak_reduce(a));
+  else if constexpr (2 * La > L_CAP) return dbl(norm(a));
+  else {
+    Fp<2 * La, 2 * Va> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] << 1;
+    r.chk();
+    return r;
+  }
+}
+
+// a - b computed as a + (K p, spread so no limb borrows) - b ; K = Vb + 1 multiples of p are added.
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto sub(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+  static_assert(BLS_SPREAD_MIN_LIMB >= BLS_SPREAD_LMAX, "spread table assumption");
+  if constexpr (Vb + 1 > BLS_SPREAD_KMAX || Va + Vb + 1 > V_CAP) {
+    if constexpr (Va > Vb) return sub(weak_reduce(a), b); else return sub(a, weak_reduce(b));
+  } else if constexpr (Lb > BLS_SPREAD_LMAX || La + Lb + 1 > L_CAP) {
+    if constexpr (La > Lb) return sub(norm(a), b); else return sub(a, norm(b));
+  } else {
+    Fp<La + Lb + 1, Va + Vb + 1> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + (BLS_SPREAD[Vb][Lb - 1][i] - b.l[i]);
+    r.chk();
+    return r;
+  }
+}
+
+template <int Lb, int Vb>
+BLS_HD auto neg(const Fp<Lb, Vb>& b) {
+  if constexpr (Vb + 1 > BLS_SPREAD_KMAX) return neg(weak_reduce(b));
+  else if constexpr (Lb > BLS_SPREAD_LMAX) return neg(norm(b));
+  else {
+    Fp<Lb + 1, Vb + 1> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = BLS_SPREAD[Vb][Lb - 1][i] - b.l[i];
+    r.chk();
+    return r;
+  }
+}
+
+// One parallel carry pass: limbs come back to 28 bits (+ at most L units), value unchanged.
+template <int L, int V>
+BLS_HD Fp<1, V> norm(const Fp<L, V>& a) {
+  Fp<1, V> r;
+  r.l[0] = a.l[0] & LMASK;
+#pragma unroll
+  for (int i = 1; i < NL - 1; ++i) r.l[i] = (a.l[i] & LMASK) + (a.l[i - 1] >> LW);
+  r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> LW);
+  r.chk();
+  return r;
+}
+
+// Cheap value reduction (about a tenth of a multiplication): subtract q*p with q estimated from the top
+// limb, computed as x + q * (2^392 - p) with the 2^392 overflow dropped.  q = floor(x_hi * M / 2^40),
+// M = floor(2^40 / (p_hi + 1)), never exceeds x / p and misses it by less than 1.01, so the result is
+// < 2.01 p (V = 2 with the slack above).  Requires V <= 64 so that x_hi * M fits 64 bits comfortably.
+constexpr uint32_t P_HI = BLS_P28[NL - 1];                               // p >> 364
+constexpr uint64_t WR_M = ((uint64_t)1 << 40) / (uint64_t)(P_HI + 1);
+
+template <int L, int V>
+BLS_HD FpR weak_reduce(const Fp<L, V>& a) {
+  static_assert(V <= 64, "weak_reduce: value bound too large for the quotient estimate");
+  const Fp<1, V> n = norm(a);
+  const uint32_t q = (uint32_t)(((uint64_t)n.l[NL - 1] * WR_M) >> 40);
+  FpR r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const uint32_t ci = (i < NL - 1) ? (LMASK - BLS_P28[i] + (i == 0 ? 1u : 0u)) : (LMASK - BLS_P28[i]);
+    acc += (uint64_t)q * ci + n.l[i];
+    r.l[i] = (uint32_t)acc & LMASK;
+    acc >>= LW;
+  }
+  r.chk();
+  return r;
+}
+
+// Make an element fit declared bounds with the cheapest sufficient step.
+template <int LT, int VT, int L, int V>
+BLS_HD auto fit(const Fp<L, V>& a) {
+  static_assert(LT >= 1 && VT >= 2, "fit: target must admit a reduced element");
+  if constexpr (V > VT) return weak_reduce(a);
+  else if constexpr (L > LT) return norm(a);
+  else return a;
+}
+
+// Bring any element back to < 2p with normalised limbs: one Montgomery multiplication by "one".
+template <int L, int V>
+BLS_HD FpR reduce(const Fp<L, V>& a) {
+  Fp<1, 1> one;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) one.l[i] = BLS_ONE_INT[i];
+  return mul(a, one);
+}
+
+// Re-label an element with bounds the type system cannot derive (checked at run time in the host
+// bound-check build, tests/hostsim).  Use only with a comment that proves the claim.
+template <int L2, int V2, int L, int V>
+BLS_HD Fp<L2, V2> assume_bounds(const Fp<L, V>& a) {
+  Fp<L2, V2> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  r.chk();
+  return r;
+}
+
+template <int L, int V>
+BLS_HD Fp<L, V> select(bool c, const Fp<L, V>& a, const Fp<L, V>& b) {   // c ? a : b
+  Fp<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+
+BLS_HD Fp<1, 1> fp_const(const uint32_t (&c)[NL]) {
+  Fp<1, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c[i];
+  return r;
+}
+BLS_HD Fp<1, 1> fp_one() { return fp_const(BLS_ONE_INT); }
+BLS_HD Fp<1, 1> fp_zero() { Fp<1, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = 0;
+  return r; }
+
+// ------------------------------------------------------------------------------------------------
+// Canonical form (only at the ABI boundary and for the exact zero tests of Mode A).
+// Input: normalised limbs, value < 2p.  Output: the unique representative in [0, p).
+BLS_HD Fp<1, 1> canonical(const FpR& a) {
+  // full carry propagation (FIPS output limbs are already < 2^28; this makes it exact for any FpR)
+  uint32_t t[NL];
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) { uint32_t v = a.l[i] + carry; t[i] = v & LMASK; carry = v >> LW; }
+  t[NL - 1] = a.l[NL - 1] + carry;
+  // s = t - p with borrow
+  uint32_t s[NL];
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t v = t[i] - BLS_P28[i] - borrow;
+    borrow = (v >> 31) & 1u;              // limbs < 2^29, so a wrap shows in bit 31
+    s[i] = (i < NL - 1) ? (v & LMASK) : v;
+  }
+  Fp<1, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = borrow ? t[i] : s[i];
+  return r;
+}
+
+// Exact zero test (the reference compares canonical arkworks values, e.g. `lambda_denominator != zero`,
+// src/miller_loop_native_optimized.rs:16).  A value < 2.02 p that is 0 mod p is one of 0, p, 2p.
+template <int L, int V>
+BLS_HD bool is_zero(const Fp<L, V>& a) {
+  const FpR r = fit<1, 2>(a);
+  uint32_t t[NL];
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) { uint32_t v = r.l[i] + carry; t[i] = v & LMASK; carry = v >> LW; }
+  t[NL - 1] = r.l[NL - 1] + carry;
+  uint32_t d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { d0 |= t[i]; d1 |= t[i] ^ BLS_P28[i]; d2 |= t[i] ^ BLS_2P28[i]; }
+  return (d0 == 0) | (d1 == 0) | (d2 == 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI conversions.  External Fp = 6 x u64 little-endian (48 bytes): either arkworks' in-memory
+// Montgomery form a * 2^384 mod p [third party] or the canonical limbs of `Bls12_381Base([u64; 6])`
+// (src/fields/bls12_381base.rs:20-21).
+BLS_HD Fp<1, 1> unpack384(const uint64_t* w) {          // 384-bit integer -> 28-bit limbs (no reduction)
+  Fp<1, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bit = LW * i, word = bit >> 6, sh = bit & 63;
+    uint64_t v = w[word] >> sh;
+    if (sh > 64 - LW && word + 1 < 6) v |= w[word + 1] << (64 - sh);
+    r.l[i] = (uint32_t)v & LMASK;
+  }
+  return r;
+}
+
+BLS_HD void pack384(uint64_t* w, const Fp<1, 1>& a) {    // canonical 28-bit limbs -> 6 x u64
+#pragma unroll
+  for (int k = 0; k < 6; ++k) w[k] = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bit = LW * i, word = bit >> 6, sh = bit & 63;
+    w[word] |= (uint64_t)a.l[i] << sh;
+    if (sh > 64 - LW && word + 1 < 6) w[word + 1] |= (uint64_t)a.l[i] >> (64 - sh);
+  }
+}
+
+enum IoForm { IO_ARK_MONT = 0, IO_CANONICAL = 1 };
+
+BLS_HD FpR fp_load(const uint64_t* w, int form) {
+  Fp<1, 1> x = unpack384(w);    // any 384-bit pattern: value < 2^384 < 10p
+  Fp<1, 10> xv;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) xv.l[i] = x.l[i];
+  Fp<1, 1> k = (form == IO_ARK_MONT) ? fp_const(BLS_C_IN_ARK) : fp_const(BLS_C_IN_CANON);
+  return mul(xv, k);
+}
+
+template <int L, int V>
+BLS_HD void fp_store(uint64_t* w, const Fp<L, V>& a, int form) {
+  Fp<1, 1> k = (form == IO_ARK_MONT) ? fp_const(BLS_C_OUT_ARK) : fp_const(BLS_RAW_ONE);
+  pack384(w, canonical(mul(a, k)));
+}
+
+// Fermat inversion a^(p-2); zero maps to zero (callers test for zero where the reference panics:
+// src/miller_loop_native_optimized.rs:102).  The exponent is a constant, so the 2-bit window walk is
+// wave-uniform control flow: 380 squarings + ~143 multiplications, table of 3 elements.
+template <int L, int V>
+BLS_HD_NOINLINE FpR fp_inv(const Fp<L, V>& a_in) {
+  const FpR a1 = reduce(a_in);
+  const FpR a2 = sqr(a1);
+  const FpR a3 = mul(a2, a1);
+  FpR r = a1;
+  bool started = false;
+  for (int w = 190; w >= 0; --w) {        // 191 windows cover bits 0..381
+    const uint32_t d = (uint32_t)(BLS_P_MINUS_2[w >> 5] >> ((w & 31) * 2)) & 3u;
+    if (started) { r = sqr(r); r = sqr(r); }
+    if (d) {
+      const FpR t = (d == 1) ? a1 : (d == 2) ? a2 : a3;
+      if (started) r = mul(r, t); else { r = t; started = true; }
+    }
+  }
+  return r;
+}
+
+}  // namespace bls

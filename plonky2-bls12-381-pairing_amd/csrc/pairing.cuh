@@ -1,0 +1,265 @@
+// Curve steps, Miller loops and pairings (one pairing per lane) for the MI355X engine.
+//
+// Two loop schedules over the same field kernels:
+//   Mode A  `miller_ref_opt`  bit-exact restatement of the reference's
+//           optimized_miller_loop(P: G1Projective, Q: G2Projective) -> Fq12
+//           (src/miller_loop_native_optimized.rs:8-127) including its quirks: LSB-first walk of the loop
+//           parameter, numerator/denominator pair, Jacobian coordinates read as homogeneous, values living
+//           in the c0.c0 slot, "final exponentiation" = one squaring.
+//   Mode B  `miller_ate` / `pairing`  the optimal-ate Miller loop the reference's
+//           src/miller_loop_native.rs:27-116 (+ commented `ell`, :118-152) specifies, and the final
+//           exponentiation of src/fields_as_trees/miller_loop.rs:128-178.
+#pragma once
+#include "tower.cuh"
+
+namespace bls {
+
+enum : uint8_t { FLAG_DEN_ZERO = 1, FLAG_INFINITY = 2 };
+
+struct G2Jac { Fp2R x, y, z; };
+struct G1Jac { FpR x, y, z; };
+struct G2Aff { Fp2R x, y; };
+struct G1Aff { FpR x, y; };
+
+// Exact zero / equality tests on field values (the reference compares canonical arkworks elements).
+template <int La, int Va, int Lb, int Vb>
+BLS_HD bool eq(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return is_zero(sub(a, b)); }
+
+// ------------------------------------------------------------------------------------- Jacobian G2
+// ark-ec 0.4.2 `Projective::double_in_place`, a = 0 (EFD dbl-2009-l) [third party; SURVEY App. A.3]
+BLS_HD_NOINLINE G2Jac g2_jac_double(const G2Jac& p) {
+  if (is_zero(p.z)) return p;
+  const Fp2R A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+  const auto D = dbl(sub(sub(sqr(add(p.x, B)), A), C));
+  const auto E = add(dbl(A), A);
+  const Fp2R F = sqr(E);
+  G2Jac r;
+  r.z = fit<1, 2>(dbl(mul(p.y, p.z)));
+  const auto X3 = fit<1, 2>(sub(sub(F, D), D));
+  r.x = X3;
+  r.y = fit<1, 2>(sub(mul(E, sub(D, X3)), dbl(dbl(dbl(C)))));
+  return r;
+}
+
+// ark-ec 0.4.2 `impl AddAssign<&Self> for Projective` (EFD add-2007-bl) [third party; SURVEY App. A.3]
+BLS_HD_NOINLINE G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) {
+  if (is_zero(p1.z)) return p2;
+  if (is_zero(p2.z)) return p1;
+  const Fp2R Z1Z1 = sqr(p1.z), Z2Z2 = sqr(p2.z);
+  const Fp2R U1 = mul(p1.x, Z2Z2), U2 = mul(p2.x, Z1Z1);
+  const Fp2R S1 = mul(mul(p1.y, p2.z), Z2Z2), S2 = mul(mul(p2.y, p1.z), Z1Z1);
+  if (eq(U1, U2) && eq(S1, S2)) return g2_jac_double(p1);
+  const auto H = sub(U2, U1);
+  const Fp2R I = sqr(dbl(H));
+  const Fp2R J = mul(H, I);
+  const auto r = dbl(sub(S2, S1));
+  const Fp2R V = mul(U1, I);
+  G2Jac o;
+  const auto X3 = fit<1, 2>(sub(sub(sqr(r), J), dbl(V)));
+  o.x = X3;
+  o.y = fit<1, 2>(sub(mul(r, sub(V, X3)), dbl(mul(S1, J))));
+  o.z = fit<1, 2>(mul(sub(sub(sqr(add(p1.z, p2.z)), Z1Z1), Z2Z2), H));
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------ Mode A
+struct LineND { Fp2R n, d; };
+
+// shared tail of branches A and T (src/miller_loop_native_optimized.rs:20-23,31 / :44-47,55)
+template <int Ln, int Vn, int Ld, int Vd>
+BLS_HD LineND line_tail(const Fp2<Ln, Vn>& num, const Fp2<Ld, Vd>& den, const G2Jac& q1, const G1Jac& p) {
+  const auto a = sub(mul_fp(q1.z, p.x), mul_fp(q1.x, p.z));      // xp z1 - x1 zp
+  const auto b = sub(mul_fp(q1.z, p.y), mul_fp(q1.y, p.z));      // yp z1 - y1 zp
+  LineND r;
+  r.n = fit<1, 2>(sub(mul(num, a), mul(den, b)));
+  r.d = mul(mul_fp(fit<1, 2>(den), p.z), q1.z);
+  return r;
+}
+
+// tangent branch, taken unconditionally for the (R, R) call: num = y z - y z and den = x z - x z are exactly
+// zero, so the reference always lands in `else if lambda_numerator == zero` (:38-61)
+BLS_HD_NOINLINE LineND line_tangent(const G2Jac& q1, const G1Jac& p) {
+  const Fp2R xx = sqr(q1.x);
+  const auto num = add(dbl(xx), xx);                               // 3 x1^2        (:39)
+  const auto den = dbl(mul(q1.y, q1.z));                           // 2 y1 z1       (:40)
+  return line_tail(num, den, q1, p);
+}
+
+// general call (R, Q): three-way branch of :14-77
+BLS_HD_NOINLINE LineND line_chord(const G2Jac& q1, const G2Jac& q2, const G1Jac& p) {
+  const auto num = fit<1, 2>(sub(mul(q2.y, q1.z), mul(q1.y, q2.z)));   // :14
+  const auto den = fit<1, 2>(sub(mul(q2.x, q1.z), mul(q1.x, q2.z)));   // :15
+  if (!is_zero(den)) return line_tail(num, den, q1, p);                 // :16-37
+  if (is_zero(num)) return line_tangent(q1, p);                        // :38-61
+  LineND r;                                                            // :62-77 vertical
+  r.n = fit<1, 2>(sub(mul_fp(q1.z, p.x), mul_fp(q1.x, p.z)));
+  r.d = mul_fp(q1.z, p.z);
+  return r;
+}
+
+BLS_HD Fp12R embed_fp2(const Fp2R& v) {        // Fq12::new(Fq6::new(v, 0, 0), Fq6::zero())  (:18-36)
+  Fp12R r;
+  r.c0 = Fp6R(v, Fp2R(fp2_zero()), Fp2R(fp2_zero()));
+  r.c1 = Fp6R(fp6_zero());
+  return r;
+}
+
+// optimized_miller_loop (:81-127).  GENERIC = true multiplies full Fq12 values like the reference does;
+// false keeps the (provably Fp2-valued) accumulators in Fp2 -- identical output bits.
+template <bool GENERIC>
+BLS_HD Fp12R miller_ref_opt(const G1Jac& p, const G2Jac& q, uint8_t& flags) {
+  G2Jac r = q;
+  flags = 0;
+  if constexpr (GENERIC) {
+    Fp12R f_num = fp12_one(), f_den = fp12_one();
+    for (int i = 0; i < 64; ++i) {                                        // :89, bit i of BLS_X, LSB first
+      const LineND t = line_tangent(r, p);                                // :90
+      f_num = mul(mul(f_num, f_num), embed_fp2(t.n));                     // :91
+      f_den = mul(mul(f_den, f_den), embed_fp2(t.d));                     // :92
+      r = g2_jac_add(r, r);                                               // :93
+      if ((BLS_X_PARAM >> i) & 1ull) {
+        const LineND c = line_chord(r, q, p);                             // :95
+        f_num = mul(f_num, embed_fp2(c.n));                               // :96
+        f_den = mul(f_den, embed_fp2(c.d));                               // :97
+        r = g2_jac_add(r, q);                                             // :98
+      }
+    }
+    if (is_zero(f_den)) { flags |= FLAG_DEN_ZERO; }                       // :102 panics in the reference
+    Fp12R f = mul(f_num, inv(f_den));                                     // :102
+    return mul(f, f);                                                     // :116-121
+  } else {
+    Fp2R f_num = fp2_one(), f_den = fp2_one();
+    for (int i = 0; i < 64; ++i) {
+      const LineND t = line_tangent(r, p);
+      f_num = mul(sqr(f_num), t.n);
+      f_den = mul(sqr(f_den), t.d);
+      r = g2_jac_add(r, r);
+      if ((BLS_X_PARAM >> i) & 1ull) {
+        const LineND c = line_chord(r, q, p);
+        f_num = mul(f_num, c.n);
+        f_den = mul(f_den, c.d);
+        r = g2_jac_add(r, q);
+      }
+    }
+    if (is_zero(f_den)) { flags |= FLAG_DEN_ZERO; }
+    const Fp2R f = mul(f_num, inv(f_den));
+    return embed_fp2(sqr(f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ Mode B
+struct LineCoeffs { Fp2R a, b, c; };     // (tmp0, tmp3, tmp6) / (t10, t1, t9)
+
+// src/miller_loop_native.rs:27-55 (Alg. 26 of ePrint 2010/354)
+BLS_HD_NOINLINE LineCoeffs doubling_step(G2Jac& r) {
+  const Fp2R tmp0 = sqr(r.x);
+  const Fp2R tmp1 = sqr(r.y);
+  const Fp2R tmp2 = sqr(tmp1);
+  const auto tmp3 = dbl(sub(sub(sqr(add(tmp1, r.x)), tmp0), tmp2));
+  const auto tmp4 = add(dbl(tmp0), tmp0);
+  const auto tmp6 = add(r.x, tmp4);
+  const Fp2R tmp5 = sqr(tmp4);
+  const Fp2R zsq = sqr(r.z);
+  const auto X3 = fit<1, 2>(sub(sub(tmp5, tmp3), tmp3));
+  const auto Z3 = fit<1, 2>(sub(sub(sqr(add(r.z, r.y)), tmp1), zsq));
+  const auto Y3 = fit<1, 2>(sub(mul(sub(tmp3, X3), tmp4), dbl(dbl(dbl(tmp2)))));
+  LineCoeffs l;
+  l.b = fit<1, 2>(neg(dbl(mul(tmp4, zsq))));                               // :44-46
+  l.c = fit<1, 2>(sub(sub(sub(sqr(tmp6), tmp0), tmp5), dbl(dbl(tmp1))));   // :47-50
+  l.a = fit<1, 2>(dbl(mul(Z3, zsq)));                                      // :51-52
+  r.x = X3; r.y = Y3; r.z = Z3;
+  return l;
+}
+
+// src/miller_loop_native.rs:58-87 (Alg. 27)
+BLS_HD_NOINLINE LineCoeffs addition_step(G2Jac& r, const G2Aff& q) {
+  const Fp2R zsq = sqr(r.z);
+  const Fp2R ysq = sqr(q.y);
+  const Fp2R t0 = mul(zsq, q.x);
+  const Fp2R t1 = mul(sub(sub(sqr(add(q.y, r.z)), ysq), zsq), zsq);
+  const auto t2 = fit<1, 2>(sub(t0, r.x));
+  const Fp2R t3 = sqr(t2);
+  const auto t4 = dbl(dbl(t3));
+  const Fp2R t5 = mul(t4, t2);
+  const auto t6 = fit<1, 2>(sub(sub(t1, r.y), r.y));
+  const Fp2R t9 = mul(t6, q.x);
+  const Fp2R t7 = mul(t4, r.x);
+  const auto X3 = fit<1, 2>(sub(sub(sub(sqr(t6), t5), t7), t7));
+  const auto Z3 = fit<1, 2>(sub(sub(sqr(add(r.z, t2)), zsq), t3));
+  const auto t10 = add(q.y, Z3);
+  const Fp2R t8 = mul(sub(t7, X3), t6);
+  const auto Y3 = fit<1, 2>(sub(t8, dbl(mul(r.y, t5))));
+  const auto t10b = sub(sub(sqr(t10), ysq), sqr(Z3));
+  LineCoeffs l;
+  l.c = fit<1, 2>(sub(dbl(t9), t10b));          // t9
+  l.a = fit<1, 2>(dbl(Z3));                     // t10
+  l.b = fit<1, 2>(dbl(neg(t6)));                // t1   (:83-84)
+  r.x = X3; r.y = Y3; r.z = Z3;
+  return l;
+}
+
+// commented `ell`, src/miller_loop_native.rs:139-152
+BLS_HD Fp12R ell(const Fp12R& f, const LineCoeffs& l, const G1Aff& p) {
+  const Fp2R c0 = mul_fp(l.a, p.y);
+  const Fp2R c1 = mul_fp(l.b, p.x);
+  return mul_by_014(f, l.c, c1, c0);
+}
+
+// Miller loop over N_PAIRS pairs with shared squarings: src/miller_loop_native.rs:89-116 driven the way
+// multi_miller_loop (:154-212) intends.  skip[j] marks a pair with a point at infinity (its lines are
+// skipped, like the commented `either_identity` select at :167-170).
+template <int N_PAIRS>
+BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
+  G2Jac r[N_PAIRS];
+#pragma unroll
+  for (int j = 0; j < N_PAIRS; ++j) { r[j].x = q[j].x; r[j].y = q[j].y; r[j].z = Fp2R(fp2_one()); }
+  Fp12R f = fp12_one();
+  // bits of BLS_X >> 1 below its leading one, MSB first (:94-98): positions 61 .. 0
+  for (int b = 61; b >= 0; --b) {
+    const bool bit = ((BLS_X_PARAM >> 1) >> b) & 1ull;
+#pragma unroll
+    for (int j = 0; j < N_PAIRS; ++j) {
+      const LineCoeffs l = doubling_step(r[j]);
+      if (!skip[j]) f = ell(f, l, p[j]);
+    }
+    if (bit) {
+#pragma unroll
+      for (int j = 0; j < N_PAIRS; ++j) {
+        const LineCoeffs l = addition_step(r[j], q[j]);
+        if (!skip[j]) f = ell(f, l, p[j]);
+      }
+    }
+    f = sqr(f);                                                           // :106
+  }
+#pragma unroll
+  for (int j = 0; j < N_PAIRS; ++j) {                                     // :109
+    const LineCoeffs l = doubling_step(r[j]);
+    if (!skip[j]) f = ell(f, l, p[j]);
+  }
+  return fit<1, 2>(conj(f));                                              // :111-113 (x < 0)
+}
+
+// ------------------------------------------------------------------------------------------- I/O
+BLS_HD G1Jac g1_jac_load(const uint64_t* w, int form) {
+  G1Jac p; p.x = fp_load(w, form); p.y = fp_load(w + 6, form); p.z = fp_load(w + 12, form); return p;
+}
+BLS_HD G2Jac g2_jac_load(const uint64_t* w, int form) {
+  G2Jac q; q.x = fp2_load(w, form); q.y = fp2_load(w + 12, form); q.z = fp2_load(w + 24, form); return q;
+}
+// affine points; the all-zero encoding (x = y = 0, not on either curve) denotes the point at infinity
+BLS_HD G1Aff g1_aff_load(const uint64_t* w, int form, bool& inf) {
+  uint64_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) o |= w[i];
+  inf = (o == 0);
+  G1Aff p; p.x = fp_load(w, form); p.y = fp_load(w + 6, form); return p;
+}
+BLS_HD G2Aff g2_aff_load(const uint64_t* w, int form, bool& inf) {
+  uint64_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) o |= w[i];
+  inf = (o == 0);
+  G2Aff q; q.x = fp2_load(w, form); q.y = fp2_load(w + 12, form); return q;
+}
+
+}  // namespace bls

@@ -1,0 +1,425 @@
+// Fp2 -> Fp6 -> Fp12 tower for the MI355X pairing engine (one pairing per lane).
+//
+// Replaces the tower arithmetic the reference takes from ark-ff `Fq2/Fq6/Fq12` [third party]; formulas
+// follow the reference's written statements of the tower:
+//   Fp2  = Fp[u]/(u^2+1)        src/fields_as_trees/fq2_target_tree.rs:54-142
+//   Fp6  = Fp2[v]/(v^3-(1+u))   src/fields_as_trees/fq6_target_tree.rs:59-293
+//   Fp12 = Fp6[w]/(w^2-v)       src/fields_as_trees/fq12_target_tree.rs:53-176
+// Field values are canonical at the ABI, so only the algebraic value matters for bit-exactness; inside,
+// every Fp2 product is two fused multiply-pairs with a single Montgomery reduction each (fp.cuh).
+//
+// Bounds <L, V> (limb / value, see fp.cuh) are carried through every type.  Functions whose results are
+// kept as loop state return "R" types (<1, 2>) by ending in fit<1, 2>().
+#pragma once
+#include "fp.cuh"
+
+// Inlining granularity of the tower (tunable: code size vs call traffic).  Default: Fp2 products inline
+// into Fp6-level routines; Fp6/Fp12-level routines are real functions.
+#ifndef BLS_INLINE_FP6
+#define BLS_INLINE_FP6 0
+#endif
+#ifndef BLS_INLINE_FP12
+#define BLS_INLINE_FP12 0
+#endif
+#if BLS_INLINE_FP6
+#define BLS_FN_FP6 BLS_HD
+#else
+#define BLS_FN_FP6 BLS_HD_NOINLINE
+#endif
+#if BLS_INLINE_FP12
+#define BLS_FN_FP12 BLS_HD
+#else
+#define BLS_FN_FP12 BLS_HD_NOINLINE
+#endif
+
+namespace bls {
+
+// ================================================================================================ Fp2
+template <int L, int V>
+struct Fp2 {
+  Fp<L, V> c0, c1;
+  Fp2() = default;
+  BLS_HD Fp2(const Fp<L, V>& a, const Fp<L, V>& b) : c0(a), c1(b) {}
+  template <int L2, int V2>
+  BLS_HD Fp2(const Fp2<L2, V2>& o) : c0(o.c0), c1(o.c1) {}
+};
+using Fp2R = Fp2<1, 2>;
+
+// build an Fp2 from two Fp of (possibly) different bounds
+template <int L0, int V0, int L1, int V1>
+BLS_HD auto make_fp2(const Fp<L0, V0>& a, const Fp<L1, V1>& b) {
+  constexpr int L = L0 > L1 ? L0 : L1;
+  constexpr int V = V0 > V1 ? V0 : V1;
+  return Fp2<L, V>(Fp<L, V>(a), Fp<L, V>(b));
+}
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto add(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return make_fp2(add(a.c0, b.c0), add(a.c1, b.c1)); }
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto sub(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return make_fp2(sub(a.c0, b.c0), sub(a.c1, b.c1)); }
+template <int L, int V>
+BLS_HD auto neg(const Fp2<L, V>& a) { return make_fp2(neg(a.c0), neg(a.c1)); }
+template <int L, int V>
+BLS_HD auto dbl(const Fp2<L, V>& a) { return make_fp2(dbl(a.c0), dbl(a.c1)); }
+template <int LT, int VT, int L, int V>
+BLS_HD auto fit(const Fp2<L, V>& a) { return make_fp2(fit<LT, VT>(a.c0), fit<LT, VT>(a.c1)); }
+template <int L, int V>
+BLS_HD Fp2<L, V> select(bool c, const Fp2<L, V>& a, const Fp2<L, V>& b) {
+  return Fp2<L, V>(select(c, a.c0, b.c0), select(c, a.c1, b.c1));
+}
+
+// Largest operand bounds the fused schoolbook product accepts: with the c1 operand of the lower-L side
+// negated (L + 1, V + 1):  La*Lb + (Lmin + 1)*Lmax <= 17  and  Va*Vb + (Vneg + 1)*Vother <= 2500.
+template <int La, int Va, int Lb, int Vb>
+struct Fp2MulFits {
+  static constexpr bool neg_a = (La <= Lb);
+  static constexpr int ll = La * Lb + (neg_a ? (La + 1) * Lb : (Lb + 1) * La);
+  static constexpr int vv = Va * Vb + (neg_a ? (Va + 1) * Vb : (Vb + 1) * Va);
+  static constexpr bool ok = ll <= MONT_LL_MAX && vv <= MONT_VV_MAX;
+};
+
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u   -- fq2_target_tree.rs:97-115
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2R mul_raw(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+  using F = Fp2MulFits<La, Va, Lb, Vb>;
+  static_assert(F::ok, "fp2 mul: operand bounds too large (fit<> them first)");
+  if constexpr (F::neg_a)
+    return Fp2R(mul2(a.c0, b.c0, neg(a.c1), b.c1), mul2(a.c0, b.c1, a.c1, b.c0));
+  else
+    return Fp2R(mul2(a.c0, b.c0, a.c1, neg(b.c1)), mul2(a.c0, b.c1, a.c1, b.c0));
+}
+
+// Multiplication with automatic operand conditioning: normalise / weakly reduce whichever operand makes
+// the fused product overflow its static bounds.
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+  if constexpr (Fp2MulFits<La, Va, Lb, Vb>::ok) return mul_raw(a, b);
+  else if constexpr (Va * Vb + (Va + 1) * Vb > MONT_VV_MAX) {
+    if constexpr (Va >= Vb) return mul(fit<1, 2>(a), b); else return mul(a, fit<1, 2>(b));
+  } else {
+    if constexpr (La >= Lb) return mul(fit<1, Va>(a), b); else return mul(a, fit<1, Vb>(b));
+  }
+}
+
+// complex squaring (a0+a1)(a0-a1), 2 a0 a1   -- fq2_target_tree.rs:80-91
+template <int L, int V>
+BLS_HD Fp2R sqr(const Fp2<L, V>& a) {
+  if constexpr ((2 * L) * (2 * L + 1) <= MONT_LL_MAX && (2 * V) * (2 * V + 1) <= MONT_VV_MAX) {
+    return Fp2R(mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1));
+  } else if constexpr ((2 * V) * (2 * V + 1) > MONT_VV_MAX) {
+    return sqr(fit<1, 2>(a));
+  } else {
+    return sqr(fit<1, V>(a));
+  }
+}
+
+// Fp2 x Fp (line evaluation scaling, src/miller_loop_native.rs:143-147 commented `ell`)
+template <int L, int V, int Lk, int Vk>
+BLS_HD Fp2R mul_fp(const Fp2<L, V>& a, const Fp<Lk, Vk>& k) { return Fp2R(mul(a.c0, k), mul(a.c1, k)); }
+
+template <int L, int V>
+BLS_HD auto conj(const Fp2<L, V>& a) { return make_fp2(a.c0, neg(a.c1)); }   // fq2_target_tree.rs:117-122
+
+// multiply by xi = 1 + u: (c0 - c1, c0 + c1)   -- fq2_target_tree.rs:137-142
+template <int L, int V>
+BLS_HD auto mul_xi(const Fp2<L, V>& a) { return make_fp2(sub(a.c0, a.c1), add(a.c0, a.c1)); }
+
+// inverse via the norm (fq2_target_tree.rs:66-78); zero maps to zero.
+template <int L, int V>
+BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
+  const Fp2R a = fit<1, 2>(a_in);
+  const FpR n = mul2(a.c0, a.c0, a.c1, a.c1);
+  const FpR ni = fp_inv(n);
+  return Fp2R(mul(a.c0, ni), mul(neg(a.c1), ni));
+}
+
+template <int L, int V>
+BLS_HD bool is_zero(const Fp2<L, V>& a) { return is_zero(a.c0) & is_zero(a.c1); }
+
+BLS_HD Fp2<1, 1> fp2_zero() { return Fp2<1, 1>(fp_zero(), fp_zero()); }
+BLS_HD Fp2<1, 1> fp2_one() { return Fp2<1, 1>(fp_one(), fp_zero()); }
+
+BLS_HD Fp2R fp2_load(const uint64_t* w, int form) { return Fp2R(fp_load(w, form), fp_load(w + 6, form)); }
+template <int L, int V>
+BLS_HD void fp2_store(uint64_t* w, const Fp2<L, V>& a, int form) { fp_store(w, a.c0, form); fp_store(w + 6, a.c1, form); }
+
+// ================================================================================================ Fp6
+template <int L, int V>
+struct Fp6 {
+  Fp2<L, V> c0, c1, c2;
+  Fp6() = default;
+  BLS_HD Fp6(const Fp2<L, V>& a, const Fp2<L, V>& b, const Fp2<L, V>& c) : c0(a), c1(b), c2(c) {}
+  template <int L2, int V2>
+  BLS_HD Fp6(const Fp6<L2, V2>& o) : c0(o.c0), c1(o.c1), c2(o.c2) {}
+};
+using Fp6R = Fp6<1, 2>;
+
+// helper: build an Fp6 from three Fp2 of different bounds (bounds = component-wise max)
+template <int L0, int V0, int L1, int V1, int L2, int V2>
+BLS_HD auto make_fp6(const Fp2<L0, V0>& a, const Fp2<L1, V1>& b, const Fp2<L2, V2>& c) {
+  constexpr int L = (L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2));
+  constexpr int V = (V0 > V1 ? (V0 > V2 ? V0 : V2) : (V1 > V2 ? V1 : V2));
+  return Fp6<L, V>(Fp2<L, V>(a), Fp2<L, V>(b), Fp2<L, V>(c));
+}
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto add(const Fp6<La, Va>& a, const Fp6<Lb, Vb>& b) {
+  return make_fp6(add(a.c0, b.c0), add(a.c1, b.c1), add(a.c2, b.c2));
+}
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto sub(const Fp6<La, Va>& a, const Fp6<Lb, Vb>& b) {
+  return make_fp6(sub(a.c0, b.c0), sub(a.c1, b.c1), sub(a.c2, b.c2));
+}
+template <int L, int V>
+BLS_HD auto neg(const Fp6<L, V>& a) { return make_fp6(neg(a.c0), neg(a.c1), neg(a.c2)); }
+template <int L, int V>
+BLS_HD auto dbl(const Fp6<L, V>& a) { return make_fp6(dbl(a.c0), dbl(a.c1), dbl(a.c2)); }
+template <int LT, int VT, int L, int V>
+BLS_HD auto fit(const Fp6<L, V>& a) { return make_fp6(fit<LT, VT>(a.c0), fit<LT, VT>(a.c1), fit<LT, VT>(a.c2)); }
+
+// multiply by v: (a, b, c) -> (c xi, a, b)   -- fq6_target_tree.rs:219-230
+template <int L, int V>
+BLS_HD auto mul_v(const Fp6<L, V>& a) { return make_fp6(mul_xi(a.c2), a.c0, a.c1); }
+
+// Karatsuba, 6 Fp2 products   -- fq6_target_tree.rs:172-214
+template <int La, int Va, int Lb, int Vb>
+BLS_FN_FP6 auto mul(const Fp6<La, Va>& a, const Fp6<Lb, Vb>& b) {
+  const Fp2R aa = mul(a.c0, b.c0), bb = mul(a.c1, b.c1), cc = mul(a.c2, b.c2);
+  const Fp2R x12 = mul(add(a.c1, a.c2), add(b.c1, b.c2));
+  const Fp2R x02 = mul(add(a.c0, a.c2), add(b.c0, b.c2));
+  const Fp2R x01 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+  auto t1 = add(mul_xi(fit<1, 64>(sub(sub(x12, bb), cc))), aa);
+  auto t3 = sub(add(sub(x02, aa), bb), cc);
+  auto t2 = add(sub(sub(x01, aa), bb), mul_xi(cc));
+  return fit<1, 64>(make_fp6(t1, t2, t3));
+}
+
+// CH-SQR2   -- fq6_target_tree.rs:270-293
+template <int L, int V>
+BLS_FN_FP6 auto sqr(const Fp6<L, V>& a) {
+  const Fp2R s0 = sqr(a.c0);
+  const Fp2R ab = mul(a.c0, a.c1);
+  const auto s1 = dbl(ab);
+  const Fp2R s2 = sqr(add(sub(a.c0, a.c1), a.c2));
+  const Fp2R bc = mul(a.c1, a.c2);
+  const auto s3 = dbl(bc);
+  const Fp2R s4 = sqr(a.c2);
+  auto c0 = add(mul_xi(s3), s0);
+  auto c1 = add(mul_xi(s4), s1);
+  auto c2 = sub(sub(add(add(s1, s2), s3), s0), s4);
+  return fit<1, 64>(make_fp6(c0, c1, c2));
+}
+
+// sparse (c0, c1, 0)   -- fq6_target_tree.rs:232-259
+template <int L, int V, int L0, int V0, int L1, int V1>
+BLS_FN_FP6 auto mul_by_01(const Fp6<L, V>& s, const Fp2<L0, V0>& c0, const Fp2<L1, V1>& c1) {
+  const Fp2R aa = mul(s.c0, c0), bb = mul(s.c1, c1);
+  auto t1 = add(mul_xi(mul(s.c2, c1)), aa);
+  auto t2 = sub(sub(mul(add(c0, c1), add(s.c0, s.c1)), aa), bb);
+  auto t3 = add(mul(s.c2, c0), bb);
+  return fit<1, 64>(make_fp6(t1, t2, t3));
+}
+
+// sparse (0, c1, 0)   -- fq6_target_tree.rs:261-268
+template <int L, int V, int L1, int V1>
+BLS_FN_FP6 auto mul_by_1(const Fp6<L, V>& s, const Fp2<L1, V1>& c1) {
+  return fit<1, 64>(make_fp6(mul_xi(mul(s.c2, c1)), mul(s.c0, c1), mul(s.c1, c1)));
+}
+
+// inverse   -- fq6_target_tree.rs:59-89 ; zero maps to zero
+template <int L, int V>
+BLS_HD_NOINLINE Fp6R inv(const Fp6<L, V>& a_in) {
+  const Fp6R a = fit<1, 2>(a_in);
+  const auto c0 = fit<1, 2>(sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2))));
+  const auto c1 = fit<1, 2>(sub(mul_xi(sqr(a.c2)), mul(a.c0, a.c1)));
+  const auto c2 = fit<1, 2>(sub(sqr(a.c1), mul(a.c0, a.c2)));
+  auto tmp = add(mul(a.c1, c2), mul(a.c2, c1));
+  auto t = add(mul_xi(tmp), mul(a.c0, c0));
+  const Fp2R ti = inv(t);
+  return Fp6R(mul(c0, ti), mul(c1, ti), mul(c2, ti));
+}
+
+BLS_HD Fp6<1, 1> fp6_zero() { return Fp6<1, 1>(fp2_zero(), fp2_zero(), fp2_zero()); }
+BLS_HD Fp6<1, 1> fp6_one() { return Fp6<1, 1>(fp2_one(), fp2_zero(), fp2_zero()); }
+
+// Frobenius   -- fq6_target_tree.rs:129-169, constants canonical (fp_consts.h)
+template <int L, int V>
+BLS_HD Fp6R frobenius(const Fp6<L, V>& a) {
+  const Fp2<1, 1> k1(fp_const(BLS_FROB6_C1_C0), fp_const(BLS_FROB6_C1_C1));
+  const Fp2<1, 1> k2(fp_const(BLS_FROB6_C2_C0), fp_const(BLS_FROB6_C2_C1));
+  return Fp6R(fit<1, 2>(conj(a.c0)), mul(conj(a.c1), k1), mul(conj(a.c2), k2));
+}
+
+// =============================================================================================== Fp12
+template <int L, int V>
+struct Fp12 {
+  Fp6<L, V> c0, c1;
+  Fp12() = default;
+  BLS_HD Fp12(const Fp6<L, V>& a, const Fp6<L, V>& b) : c0(a), c1(b) {}
+  template <int L2, int V2>
+  BLS_HD Fp12(const Fp12<L2, V2>& o) : c0(o.c0), c1(o.c1) {}
+};
+using Fp12R = Fp12<1, 2>;
+
+template <int L0, int V0, int L1, int V1>
+BLS_HD auto make_fp12(const Fp6<L0, V0>& a, const Fp6<L1, V1>& b) {
+  constexpr int L = L0 > L1 ? L0 : L1;
+  constexpr int V = V0 > V1 ? V0 : V1;
+  return Fp12<L, V>(Fp6<L, V>(a), Fp6<L, V>(b));
+}
+template <int LT, int VT, int L, int V>
+BLS_HD auto fit(const Fp12<L, V>& a) {
+  auto x = fit<LT, VT>(a.c0); auto y = fit<LT, VT>(a.c1);
+  return make_fp12(x, y);
+}
+
+BLS_HD Fp12<1, 1> fp12_one() { return Fp12<1, 1>(fp6_one(), fp6_zero()); }
+
+// Karatsuba over Fp6   -- fq12_target_tree.rs:130-141
+template <int La, int Va, int Lb, int Vb>
+BLS_FN_FP12 Fp12R mul(const Fp12<La, Va>& a, const Fp12<Lb, Vb>& b) {
+  const auto aa = mul(a.c0, b.c0);
+  const auto bb = mul(a.c1, b.c1);
+  const auto x = mul(fit<1, 64>(add(a.c1, a.c0)), fit<1, 64>(add(b.c0, b.c1)));
+  const auto c1 = sub(sub(x, fit<1, 2>(aa)), fit<1, 2>(bb));
+  const auto c0 = add(mul_v(fit<1, 2>(bb)), fit<1, 2>(aa));
+  return Fp12R(fit<1, 2>(c0), fit<1, 2>(c1));
+}
+
+// complex squaring   -- fq12_target_tree.rs:143-155
+template <int L, int V>
+BLS_FN_FP12 Fp12R sqr(const Fp12<L, V>& a) {
+  const auto ab = fit<1, 2>(mul(a.c0, a.c1));
+  const auto s = fit<1, 64>(add(a.c0, a.c1));
+  const auto t = fit<1, 64>(add(mul_v(a.c1), a.c0));
+  const auto m = mul(t, s);
+  const auto c0 = sub(sub(m, ab), mul_v(ab));
+  const auto c1 = dbl(ab);
+  return Fp12R(fit<1, 2>(c0), fit<1, 2>(c1));
+}
+
+template <int L, int V>
+BLS_HD auto conj(const Fp12<L, V>& a) { return make_fp12(a.c0, neg(a.c1)); }    // fq12_target_tree.rs:53-58
+
+// inverse   -- fq12_target_tree.rs:77-90 ; zero maps to zero
+template <int L, int V>
+BLS_HD_NOINLINE Fp12R inv(const Fp12<L, V>& a_in) {
+  const Fp12R a = fit<1, 2>(a_in);
+  const auto t = sub(fit<1, 2>(sqr(a.c0)), fit<1, 2>(mul_v(fit<1, 2>(sqr(a.c1)))));
+  const Fp6R ti = inv(t);
+  return Fp12R(fit<1, 2>(mul(a.c0, ti)), fit<1, 2>(mul(a.c1, neg(ti))));
+}
+
+// Frobenius   -- fq12_target_tree.rs:92-128
+template <int L, int V>
+BLS_FN_FP12 Fp12R frobenius(const Fp12<L, V>& a) {
+  const Fp2<1, 1> k(fp_const(BLS_FROB12_C1_C0), fp_const(BLS_FROB12_C1_C1));
+  const Fp6R c0 = frobenius(a.c0);
+  const Fp6R c1 = frobenius(a.c1);
+  return Fp12R(c0, Fp6R(mul(c1.c0, k), mul(c1.c1, k), mul(c1.c2, k)));
+}
+
+// sparse multiplication by (c0, c1, 0 | 0, c4, 0)   -- fq12_target_tree.rs:157-176 (commented twin at
+// src/miller_loop_native.rs:118-137)
+template <int L, int V, int L0, int V0, int L1, int V1, int L4, int V4>
+BLS_FN_FP12 Fp12R mul_by_014(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const Fp2<L1, V1>& c1, const Fp2<L4, V4>& c4) {
+  const auto aa = fit<1, 2>(mul_by_01(f.c0, c0, c1));
+  const auto bb = fit<1, 2>(mul_by_1(f.c1, c4));
+  const auto o = add(c1, c4);
+  const auto x = mul_by_01(fit<1, 64>(add(f.c1, f.c0)), c0, o);
+  const auto r1 = sub(sub(x, aa), bb);
+  const auto r0 = add(mul_v(bb), aa);
+  return Fp12R(fit<1, 2>(r0), fit<1, 2>(r1));
+}
+
+// ---- cyclotomic subgroup (final exponentiation)   -- src/fields_as_trees/miller_loop.rs:29-126
+template <class A, class B> struct Pair2 { A a; B b; };
+template <class A, class B> BLS_HD Pair2<A, B> pair2(const A& a, const B& b) { return Pair2<A, B>{a, b}; }
+
+// (a + b s)^2 in Fp4 = Fp2[s]/(s^2 - xi)   -- miller_loop.rs:29-44
+template <int L, int V>
+BLS_HD auto fp4_square(const Fp2<L, V>& a, const Fp2<L, V>& b) {
+  const Fp2R t0 = sqr(a), t1 = sqr(b);
+  const auto c0 = add(mul_xi(t1), t0);
+  const Fp2R t2 = sqr(add(a, b));
+  const auto c1 = sub(sub(t2, t0), t1);
+  return pair2(c0, c1);
+}
+
+// Granger-Scott squaring   -- miller_loop.rs:46-104
+template <int L, int V>
+BLS_FN_FP12 Fp12R cyclotomic_square(const Fp12<L, V>& f) {
+  const auto& z0 = f.c0.c0; const auto& z4 = f.c0.c1; const auto& z3 = f.c0.c2;
+  const auto& z2 = f.c1.c0; const auto& z1 = f.c1.c1; const auto& z5 = f.c1.c2;
+  const auto A = fp4_square(z0, z1);
+  const auto n0 = add(dbl(sub(A.a, z0)), A.a);          // 2(t0 - z0) + t0
+  const auto n1 = add(dbl(add(A.b, z1)), A.b);          // 2(t1 + z1) + t1
+  const auto B = fp4_square(z2, z3);
+  const auto C = fp4_square(z4, z5);
+  const auto n4 = add(dbl(sub(B.a, z4)), B.a);
+  const auto n5 = add(dbl(add(B.b, z5)), B.b);
+  const auto t0 = mul_xi(fit<1, 2>(C.b));
+  const auto n2 = add(dbl(add(t0, z2)), t0);
+  const auto n3 = add(dbl(sub(C.a, z3)), C.a);
+  return Fp12R(Fp6R(fit<1, 2>(n0), fit<1, 2>(n4), fit<1, 2>(n3)),
+               Fp6R(fit<1, 2>(n2), fit<1, 2>(n1), fit<1, 2>(n5)));
+}
+
+// conj(f^|x|), MSB-first square-and-multiply over BLS_X   -- miller_loop.rs:106-126, with the product the
+// reference drops at :121 kept.
+BLS_HD_NOINLINE Fp12R cyclotomic_exp(const Fp12R& f) {
+  Fp12R tmp = f;                                           // leading one bit
+  for (int b = 62; b >= 0; --b) {
+    tmp = cyclotomic_square(tmp);
+    if ((BLS_X_PARAM >> b) & 1ull) tmp = mul(tmp, f);
+  }
+  return fit<1, 2>(conj(tmp));
+}
+
+// easy part + hard part   -- miller_loop.rs:166-178, :128-164 ; `ok` is false when f == 0 (no inverse)
+BLS_HD_NOINLINE Fp12R final_exponentiation(const Fp12R& f) {
+  const Fp12R t0f = fit<1, 2>(conj(f));                   // frobenius^6 == conjugation (:168-174)
+  Fp12R t1 = inv(f);                                      // :175
+  Fp12R t2 = mul(t0f, t1);                                // :133
+  t1 = t2;
+  t2 = mul(frobenius(frobenius(t2)), t1);                 // :135-136
+  t1 = fit<1, 2>(conj(cyclotomic_square(t2)));            // :137
+  Fp12R t3 = cyclotomic_exp(t2);
+  Fp12R t4 = cyclotomic_square(t3);
+  Fp12R t5 = mul(t1, t3);
+  t1 = cyclotomic_exp(t5);
+  Fp12R t0 = cyclotomic_exp(t1);
+  Fp12R t6 = cyclotomic_exp(t0);
+  t6 = mul(t6, t4);
+  t4 = cyclotomic_exp(t6);
+  t5 = fit<1, 2>(conj(t5));
+  t4 = mul(t4, mul(t5, t2));
+  t5 = fit<1, 2>(conj(t2));
+  t1 = mul(t1, t2);
+  t1 = frobenius(frobenius(frobenius(t1)));
+  t6 = mul(t6, t5);
+  t6 = frobenius(t6);
+  t3 = mul(t3, t0);
+  t3 = frobenius(frobenius(t3));
+  t3 = mul(t3, t1);
+  t3 = mul(t3, t6);
+  return mul(t3, t4);
+}
+
+template <int L, int V>
+BLS_HD bool is_zero(const Fp6<L, V>& a) { return is_zero(a.c0) & is_zero(a.c1) & is_zero(a.c2); }
+template <int L, int V>
+BLS_HD bool is_zero(const Fp12<L, V>& a) { return is_zero(a.c0) & is_zero(a.c1); }
+
+BLS_HD Fp12R fp12_load(const uint64_t* w, int form) {
+  Fp12R r;
+  r.c0.c0 = fp2_load(w, form);      r.c0.c1 = fp2_load(w + 12, form); r.c0.c2 = fp2_load(w + 24, form);
+  r.c1.c0 = fp2_load(w + 36, form); r.c1.c1 = fp2_load(w + 48, form); r.c1.c2 = fp2_load(w + 60, form);
+  return r;
+}
+// arkworks in-memory coefficient order c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1 (12 x 48 bytes)
+template <int L, int V>
+BLS_HD void fp12_store(uint64_t* w, const Fp12<L, V>& a, int form) {
+  fp2_store(w, a.c0.c0, form);      fp2_store(w + 12, a.c0.c1, form); fp2_store(w + 24, a.c0.c2, form);
+  fp2_store(w + 36, a.c1.c0, form); fp2_store(w + 48, a.c1.c1, form); fp2_store(w + 60, a.c1.c2, form);
+}
+
+}  // namespace bls

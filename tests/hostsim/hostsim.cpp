@@ -1,0 +1,171 @@
+// TEST INFRASTRUCTURE -- not product code, never linked into libbls381_hip.so.
+//
+// Compiles the device headers (plonky2-bls12-381-pairing_amd/csrc/*.cuh) for the HOST with g++ and
+// -DBLS_BOUND_CHECK so the `-m "not gpu"` suite can (1) check the kernels' algorithms against the oracle
+// without a GPU and (2) verify at run time every static limb/value bound the lazy-reduction types claim.
+// The product library has no CPU path: it fails loudly without a GPU.
+#define BLS_BOUND_CHECK 1
+#include "pairing.cuh"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace bls {
+
+static long g_checks = 0;
+static int g_max_l_seen = 0;
+
+void bound_check_fail(const char* what) {
+  fprintf(stderr, "hostsim: BOUND VIOLATION: %s\n", what);
+  abort();
+}
+
+// value < V * 1.01 * p  and  limb_i < L * 2^28 + 64 (top limb: value bound only)
+void bound_check(const uint32_t* l, int L, int V) {
+  ++g_checks;
+  for (int i = 0; i < NL - 1; ++i) {
+    if ((uint64_t)l[i] >= (uint64_t)L * (1ull << LW) + 64) {
+      char buf[128]; snprintf(buf, sizeof buf, "limb %d = 0x%x exceeds L = %d", i, l[i], L);
+      bound_check_fail(buf);
+    }
+  }
+  // exact value as 15 x 28-bit normalised limbs
+  uint64_t v[NL + 1];
+  uint64_t carry = 0;
+  for (int i = 0; i < NL; ++i) { uint64_t s = (uint64_t)l[i] + carry; v[i] = s & LMASK; carry = s >> LW; }
+  v[NL] = carry;
+  // bound = floor(V * 1.01 * p) ~ V*p + V*p/100 : compute V*101*p and compare 100*value
+  uint64_t b[NL + 2] = {0}, x[NL + 2] = {0};
+  carry = 0;
+  for (int i = 0; i < NL; ++i) { uint64_t s = (uint64_t)BLS_P28[i] * (uint64_t)(V * 101) + carry; b[i] = s & LMASK; carry = s >> LW; }
+  b[NL] = carry & LMASK; b[NL + 1] = carry >> LW;
+  carry = 0;
+  for (int i = 0; i <= NL; ++i) { uint64_t s = v[i] * 100ull + carry; x[i] = s & LMASK; carry = s >> LW; }
+  x[NL + 1] = carry;
+  for (int i = NL + 1; i >= 0; --i) {
+    if (x[i] < b[i]) return;
+    if (x[i] > b[i]) { char buf[128]; snprintf(buf, sizeof buf, "value exceeds V = %d (x 1.01 p)", V); bound_check_fail(buf); }
+  }
+  bound_check_fail("value equals the bound");
+}
+
+}  // namespace bls
+
+using namespace bls;
+
+extern "C" {
+
+long hostsim_bound_checks() { return bls::g_checks; }
+
+// op codes shared with include/bls381_hip.h
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_INV = 4, OP_NEG = 5, OP_TO_MONT = 6, OP_FROM_MONT = 7 };
+
+int hostsim_fp_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    if (op == OP_TO_MONT) { FpR x = fp_load(a + 6 * i, IO_CANONICAL); fp_store(out + 6 * i, x, IO_ARK_MONT); continue; }
+    if (op == OP_FROM_MONT) { FpR x = fp_load(a + 6 * i, IO_ARK_MONT); fp_store(out + 6 * i, x, IO_CANONICAL); continue; }
+    FpR x = fp_load(a + 6 * i, form);
+    FpR y = b ? fp_load(b + 6 * i, form) : x;
+    switch (op) {
+      case OP_ADD: fp_store(out + 6 * i, add(x, y), form); break;
+      case OP_SUB: fp_store(out + 6 * i, sub(x, y), form); break;
+      case OP_MUL: fp_store(out + 6 * i, mul(x, y), form); break;
+      case OP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
+      case OP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
+      case OP_NEG: fp_store(out + 6 * i, neg(x), form); break;
+      default: return 1;
+    }
+  }
+  return 0;
+}
+
+enum { OP2_MUL = 0, OP2_SQR = 1, OP2_INV = 2, OP2_MUL_XI = 3, OP2_CONJ = 4 };
+int hostsim_fp2_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    Fp2R x = fp2_load(a + 12 * i, form);
+    Fp2R y = b ? fp2_load(b + 12 * i, form) : x;
+    switch (op) {
+      case OP2_MUL: fp2_store(out + 12 * i, mul(x, y), form); break;
+      case OP2_SQR: fp2_store(out + 12 * i, sqr(x), form); break;
+      case OP2_INV: fp2_store(out + 12 * i, inv(x), form); break;
+      case OP2_MUL_XI: fp2_store(out + 12 * i, mul_xi(x), form); break;
+      case OP2_CONJ: fp2_store(out + 12 * i, conj(x), form); break;
+      default: return 1;
+    }
+  }
+  return 0;
+}
+
+enum { OP12_MUL = 0, OP12_SQR = 1, OP12_INV = 2, OP12_FROBENIUS = 3, OP12_CYC_SQR = 4, OP12_CONJ = 5,
+       OP12_CYC_EXP = 6, OP12_FINAL_EXP = 7 };
+int hostsim_fp12_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    Fp12R x = fp12_load(a + 72 * i, form);
+    Fp12R y = b ? fp12_load(b + 72 * i, form) : x;
+    Fp12R r;
+    switch (op) {
+      case OP12_MUL: r = mul(x, y); break;
+      case OP12_SQR: r = sqr(x); break;
+      case OP12_INV: r = inv(x); break;
+      case OP12_FROBENIUS: r = frobenius(x); break;
+      case OP12_CYC_SQR: r = cyclotomic_square(x); break;
+      case OP12_CONJ: r = fit<1, 2>(conj(x)); break;
+      case OP12_CYC_EXP: r = cyclotomic_exp(x); break;
+      case OP12_FINAL_EXP: r = final_exponentiation(x); break;
+      default: return 1;
+    }
+    fp12_store(out + 72 * i, r, form);
+  }
+  return 0;
+}
+
+int hostsim_miller_ref_opt(int form, int generic, const uint64_t* g1, const uint64_t* g2, uint64_t* out,
+                           uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    G1Jac p = g1_jac_load(g1 + 18 * i, form);
+    G2Jac q = g2_jac_load(g2 + 36 * i, form);
+    uint8_t fl = 0;
+    Fp12R f = generic ? miller_ref_opt<true>(p, q, fl) : miller_ref_opt<false>(p, q, fl);
+    fp12_store(out + 72 * i, f, form);
+    if (flags) flags[i] = fl;
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+template <int K>
+static void multi_one(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flag) {
+  G1Aff p[K]; G2Aff q[K]; bool skip[K];
+  uint8_t fl = 0;
+  for (int j = 0; j < K; ++j) {
+    bool i1, i2;
+    p[j] = g1_aff_load(g1 + 12 * j, form, i1);
+    q[j] = g2_aff_load(g2 + 24 * j, form, i2);
+    skip[j] = i1 || i2;
+    if (skip[j]) fl |= FLAG_INFINITY;
+  }
+  Fp12R f = miller_ate<K>(p, q, skip);
+  if (with_final_exp) f = final_exponentiation(f);
+  fp12_store(out, f, form);
+  if (flag) *flag = fl;
+}
+
+extern "C" {
+
+int hostsim_multi_miller(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, size_t k,
+                         uint64_t* out, uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t* a = g1 + 12 * k * i; const uint64_t* b = g2 + 24 * k * i;
+    uint8_t* fl = flags ? flags + i : nullptr;
+    switch (k) {
+      case 1: multi_one<1>(form, with_final_exp, a, b, out + 72 * i, fl); break;
+      case 2: multi_one<2>(form, with_final_exp, a, b, out + 72 * i, fl); break;
+      case 3: multi_one<3>(form, with_final_exp, a, b, out + 72 * i, fl); break;
+      default: return 1;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"
