@@ -1,0 +1,123 @@
+/* bls381_hip.h -- C ABI of libbls381_hip.so: batched BLS12-381 pairing engine for AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the native pairing path of NikolayKostadinov21/plonky2-bls12-381-pairing.
+ * The reference has no FFI of its own; each entry point below replaces one Rust item (paths relative to the
+ * reference repository) and is what a Rust `extern "C"` block would bind:
+ *
+ *   bls381_miller_ref_opt_batch   <- pub fn optimized_miller_loop(P: G1Projective, Q: G2Projective) -> Fq12
+ *                                    src/miller_loop_native_optimized.rs:81-127 (line fn :8-78)
+ *   bls381_multi_miller_batch     <- pub fn multi_miller_loop(terms: &[(&G1Affine, &G2Affine)]) -> MillerLoopResult
+ *                                    src/miller_loop_native.rs:154-212, loop :89-116, steps :27-87, `ell` :118-152
+ *   bls381_multi_pairing_batch    <- the same followed by MillerLoopResult::final_exponentiation
+ *                                    src/fields_as_trees/miller_loop.rs:128-178
+ *   bls381_final_exp_batch        <- final_exponentiation / f_conversion, same file :128-178
+ *   bls381_fp_op_batch            <- Fq / Bls12_381Base operators, src/fields/bls12_381base.rs:174-268, :118-125
+ *   bls381_fp12_op_batch          <- Fq12 operators used at src/miller_loop_native_optimized.rs:91-102,118 and
+ *                                    the tower routines of src/fields_as_trees/fq12_target_tree.rs:53-176
+ *
+ * Conventions
+ *   - All buffers are caller-owned; no allocation crosses the boundary.  `_batch` entry points take HOST
+ *     pointers and copy; `_batch_dev` twins take DEVICE pointers (hipMalloc'ed on the context's device) and
+ *     enqueue on the context's stream without synchronising (bls381_sync waits).
+ *   - Fp element = 6 x uint64_t, little-endian limbs (48 bytes).  Default encoding is the arkworks in-memory
+ *     Montgomery form a * 2^384 mod p [ark-ff 0.4.2]; BLS381_OPT_IO_FORM = BLS381_IO_CANONICAL switches to the
+ *     canonical limbs of `Bls12_381Base(pub [u64; 6])` (src/fields/bls12_381base.rs:20-21).
+ *     Fp2 = (c0, c1); Fp6 = (c0, c1, c2); Fp12 = (c0, c1): 12 Fp in the order c0.c0.c0, c0.c0.c1, c0.c1.c0, ...
+ *     G1 Jacobian = (x, y, z) 3 Fp; G2 Jacobian = (x, y, z) 3 Fp2; affine = (x, y).  An affine point whose
+ *     coordinates are all zero denotes the point at infinity (arkworks' `infinity` flag).
+ *   - Return value 0 = success, otherwise a BLS381_E_* code (bls381_strerror).  Where the reference would
+ *     panic, the element's output is zeroed and its flags[i] byte says why; flags may be NULL.
+ *   - Results are bit-identical for every batch size, device and option setting.
+ *   - A context is bound to ONE device; multi-GPU use = one context (normally one process) per GPU with the
+ *     batch split in contiguous ranges -- elements are independent, nothing is exchanged between devices.
+ */
+#ifndef BLS381_HIP_H
+#define BLS381_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bls381_ctx bls381_ctx;
+
+enum {
+  BLS381_OK = 0,
+  BLS381_E_INVALID = 1,     /* bad argument (NULL buffer, unsupported k, unknown op/option) */
+  BLS381_E_NO_DEVICE = 2,   /* no usable gfx950 device / HIP runtime failure at create */
+  BLS381_E_HIP = 3,         /* HIP runtime error during a call (bls381_last_hip_error) */
+  BLS381_E_NOMEM = 4        /* device allocation failed */
+};
+
+/* per-element flag bits */
+enum {
+  BLS381_FLAG_DEN_ZERO = 1, /* Mode A: f_den == 0, the reference panics at opt.rs:102; output zeroed */
+  BLS381_FLAG_INFINITY = 2  /* an input point at infinity: pair skipped (result 1 if all pairs skipped) */
+};
+
+enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2 };
+enum { BLS381_IO_ARK_MONT = 0, BLS381_IO_CANONICAL = 1 };
+
+/* Fp ops (first-kernel surface).  b may be NULL for unary ops. */
+enum { BLS381_FP_ADD = 0, BLS381_FP_SUB = 1, BLS381_FP_MUL = 2, BLS381_FP_SQR = 3, BLS381_FP_INV = 4,
+       BLS381_FP_NEG = 5, BLS381_FP_TO_MONT = 6, BLS381_FP_FROM_MONT = 7 };
+/* Fp12 ops */
+enum { BLS381_FP12_MUL = 0, BLS381_FP12_SQR = 1, BLS381_FP12_INV = 2, BLS381_FP12_FROBENIUS = 3,
+       BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6 };
+
+/* lifecycle ------------------------------------------------------------------------------------------ */
+int bls381_create(bls381_ctx** out, int device_id);
+void bls381_destroy(bls381_ctx* ctx);
+int bls381_set_option(bls381_ctx* ctx, int option, int value);
+int bls381_get_option(const bls381_ctx* ctx, int option, int* value);
+/* adopt an existing hipStream_t (e.g. the caller framework's current stream); NULL restores the own stream */
+int bls381_set_stream(bls381_ctx* ctx, void* hip_stream);
+int bls381_sync(bls381_ctx* ctx);
+const char* bls381_strerror(int code);
+int bls381_last_hip_error(const bls381_ctx* ctx);
+/* average device time of the last launch of the named kernel family on this context, in ms (HIP events
+ * recorded on the context's stream around the launch); < 0 if none.  kernel: 0 ref_opt, 1 miller, 2 pairing */
+float bls381_last_kernel_ms(const bls381_ctx* ctx);
+
+/* Mode A: optimized_miller_loop over a batch (src/miller_loop_native_optimized.rs:81).
+ * g1_jac: n x 3 x 6 u64, g2_jac: n x 3 x 2 x 6, out_fq12: n x 12 x 6, flags: n bytes or NULL. */
+int bls381_miller_ref_opt_batch(bls381_ctx* ctx, const uint64_t* g1_jac, const uint64_t* g2_jac,
+                                uint64_t* out_fq12, uint8_t* flags, size_t n);
+int bls381_miller_ref_opt_batch_dev(bls381_ctx* ctx, const uint64_t* g1_jac, const uint64_t* g2_jac,
+                                    uint64_t* out_fq12, uint8_t* flags, size_t n);
+
+/* Mode B: product over k pairs of optimal-ate Miller loops (src/miller_loop_native.rs:154), k in 1..4.
+ * g1_aff: n x k x 2 x 6, g2_aff: n x k x 2 x 2 x 6, out: n x 12 x 6. */
+int bls381_multi_miller_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
+                              uint64_t* out_fq12, uint8_t* flags, size_t n);
+int bls381_multi_miller_batch_dev(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
+                                  uint64_t* out_fq12, uint8_t* flags, size_t n);
+/* ... followed by the final exponentiation: full pairings / pairing products (Groth16 shape: k = 3) */
+int bls381_multi_pairing_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
+                               uint64_t* out_gt, uint8_t* flags, size_t n);
+int bls381_multi_pairing_batch_dev(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
+                                   uint64_t* out_gt, uint8_t* flags, size_t n);
+/* k = 1 conveniences */
+int bls381_miller_ate_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff,
+                            uint64_t* out_fq12, uint8_t* flags, size_t n);
+int bls381_pairing_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff,
+                         uint64_t* out_gt, uint8_t* flags, size_t n);
+
+/* final exponentiation alone (src/fields_as_trees/miller_loop.rs:166-178) */
+int bls381_final_exp_batch(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_t* out_gt, uint8_t* flags, size_t n);
+int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_t* out_gt, uint8_t* flags, size_t n);
+
+/* field-level surfaces */
+int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+/* What src/miller_loop_native.rs:154-212 returns TODAY for any input (its line steps are commented out):
+ * Fq12::one().  Host-only, here so that a caller can reproduce the literal reference behaviour. */
+int bls381_multi_miller_literal(bls381_ctx* ctx, uint64_t* out_fq12, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLS381_HIP_H */

@@ -1,0 +1,393 @@
+// libbls381_hip.so -- HIP kernels (gfx950) and the C ABI of include/bls381_hip.h.
+//
+// One pairing per lane; a workgroup is `block` lanes (default one 64-lane wave).  Each entry point cites
+// the reference item it replaces in include/bls381_hip.h.  There is NO host fallback: without a HIP device
+// bls381_create fails with BLS381_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/bls381_hip.h"
+#include "pairing.cuh"
+
+using namespace bls;
+
+// ------------------------------------------------------------------------------------------ kernels
+#ifndef BLS_MAX_BLOCK
+#define BLS_MAX_BLOCK 256
+#endif
+
+template <bool GENERIC>
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_miller_ref_opt(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
+                 uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G1Jac p = g1_jac_load(g1 + 18 * i, form);
+  const G2Jac q = g2_jac_load(g2 + 36 * i, form);
+  uint8_t fl = 0;
+  const Fp12R f = miller_ref_opt<GENERIC>(p, q, fl);
+  fp12_store(out + 72 * i, f, form);
+  if (flags) flags[i] = fl;
+}
+
+template <int K, bool FINAL_EXP>
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
+               uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Aff p[K]; G2Aff q[K]; bool skip[K];
+  uint8_t fl = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    bool i1, i2;
+    p[j] = g1_aff_load(g1 + 12 * (K * i + j), form, i1);
+    q[j] = g2_aff_load(g2 + 24 * (K * i + j), form, i2);
+    skip[j] = i1 || i2;
+    if (skip[j]) fl |= FLAG_INFINITY;
+  }
+  Fp12R f = miller_ate<K>(p, q, skip);
+  if (FINAL_EXP) f = final_exponentiation(f);
+  fp12_store(out + 72 * i, f, form);
+  if (flags) flags[i] = fl;
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_final_exp(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fp12R f = fp12_load(in + 72 * i, form);
+  fp12_store(out + 72 * i, final_exponentiation(f), form);
+  if (flags) flags[i] = 0;
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op == BLS381_FP_TO_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_CANONICAL), IO_ARK_MONT); return; }
+  if (op == BLS381_FP_FROM_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_ARK_MONT), IO_CANONICAL); return; }
+  const FpR x = fp_load(a + 6 * i, form);
+  const FpR y = b ? fp_load(b + 6 * i, form) : x;
+  switch (op) {
+    case BLS381_FP_ADD: fp_store(out + 6 * i, add(x, y), form); break;
+    case BLS381_FP_SUB: fp_store(out + 6 * i, sub(x, y), form); break;
+    case BLS381_FP_MUL: fp_store(out + 6 * i, mul(x, y), form); break;
+    case BLS381_FP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
+    case BLS381_FP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
+    case BLS381_FP_NEG: fp_store(out + 6 * i, neg(x), form); break;
+    default: break;
+  }
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp12_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fp12R x = fp12_load(a + 72 * i, form);
+  Fp12R r = x;
+  switch (op) {
+    case BLS381_FP12_MUL: { const Fp12R y = b ? fp12_load(b + 72 * i, form) : x; r = mul(x, y); break; }
+    case BLS381_FP12_SQR: r = sqr(x); break;
+    case BLS381_FP12_INV: r = inv(x); break;
+    case BLS381_FP12_FROBENIUS: r = frobenius(x); break;
+    case BLS381_FP12_CYCLOTOMIC_SQR: r = cyclotomic_square(x); break;
+    case BLS381_FP12_CONJ: r = fit<1, 2>(conj(x)); break;
+    case BLS381_FP12_CYCLOTOMIC_EXP: r = cyclotomic_exp(x); break;
+    default: break;
+  }
+  fp12_store(out + 72 * i, r, form);
+}
+
+__global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp12_store(out + 72 * i, Fp12R(fp12_one()), form);
+}
+
+// ------------------------------------------------------------------------------------------ context
+struct bls381_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int io_form = BLS381_IO_ARK_MONT;
+  int fp2_shortcut = 0;
+  int block = 64;
+  int last_hip = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                        \
+  do {                                                            \
+    hipError_t e_ = (expr);                                       \
+    if (e_ != hipSuccess) { (ctx)->last_hip = (int)e_; return (e_ == hipErrorOutOfMemory) ? BLS381_E_NOMEM : BLS381_E_HIP; } \
+  } while (0)
+
+extern "C" {
+
+const char* bls381_strerror(int code) {
+  switch (code) {
+    case BLS381_OK: return "ok";
+    case BLS381_E_INVALID: return "invalid argument";
+    case BLS381_E_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case BLS381_E_HIP: return "HIP runtime error";
+    case BLS381_E_NOMEM: return "device allocation failed";
+    default: return "unknown error";
+  }
+}
+
+int bls381_create(bls381_ctx** out, int device_id) {
+  if (!out) return BLS381_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BLS381_E_NO_DEVICE;
+  if (device_id < 0 || device_id >= count) return BLS381_E_INVALID;
+  bls381_ctx* c = new (std::nothrow) bls381_ctx();
+  if (!c) return BLS381_E_NOMEM;
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return BLS381_E_NO_DEVICE;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return BLS381_OK;
+}
+
+void bls381_destroy(bls381_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int bls381_set_option(bls381_ctx* c, int option, int value) {
+  if (!c) return BLS381_E_INVALID;
+  switch (option) {
+    case BLS381_OPT_IO_FORM:
+      if (value != BLS381_IO_ARK_MONT && value != BLS381_IO_CANONICAL) return BLS381_E_INVALID;
+      c->io_form = value; return BLS381_OK;
+    case BLS381_OPT_REF_OPT_FP2_SHORTCUT: c->fp2_shortcut = value ? 1 : 0; return BLS381_OK;
+    case BLS381_OPT_BLOCK_SIZE:
+      if (value != 64 && value != 128 && value != 256) return BLS381_E_INVALID;
+      c->block = value; return BLS381_OK;
+    default: return BLS381_E_INVALID;
+  }
+}
+
+int bls381_get_option(const bls381_ctx* c, int option, int* value) {
+  if (!c || !value) return BLS381_E_INVALID;
+  switch (option) {
+    case BLS381_OPT_IO_FORM: *value = c->io_form; return BLS381_OK;
+    case BLS381_OPT_REF_OPT_FP2_SHORTCUT: *value = c->fp2_shortcut; return BLS381_OK;
+    case BLS381_OPT_BLOCK_SIZE: *value = c->block; return BLS381_OK;
+    default: return BLS381_E_INVALID;
+  }
+}
+
+int bls381_set_stream(bls381_ctx* c, void* s) {
+  if (!c) return BLS381_E_INVALID;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return BLS381_OK;
+}
+
+int bls381_sync(bls381_ctx* c) {
+  if (!c) return BLS381_E_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BLS381_OK;
+}
+
+int bls381_last_hip_error(const bls381_ctx* c) { return c ? c->last_hip : 0; }
+
+float bls381_last_kernel_ms(const bls381_ctx* c) {
+  if (!c || !c->timed) return -1.0f;
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ launches
+namespace {
+
+inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+struct Timed {
+  bls381_ctx* c;
+  explicit Timed(bls381_ctx* c_) : c(c_) { (void)hipEventRecord(c->ev0, c->stream); }
+  ~Timed() { (void)hipEventRecord(c->ev1, c->stream); c->timed = true; }
+};
+
+int launch_ref_opt(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  if (n == 0) return BLS381_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  {
+    Timed t(c);
+    if (c->fp2_shortcut)
+      hipLaunchKernelGGL(k_miller_ref_opt<false>, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, g1, g2, out, flags, n, c->io_form);
+    else
+      hipLaunchKernelGGL(k_miller_ref_opt<true>, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, g1, g2, out, flags, n, c->io_form);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return BLS381_OK;
+}
+
+template <bool FE>
+int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (n == 0) return BLS381_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const dim3 g(grid_for(n, c->block)), b(c->block);
+  {
+    Timed t(c);
+    switch (k) {
+      case 1: hipLaunchKernelGGL((k_multi_miller<1, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
+      case 2: hipLaunchKernelGGL((k_multi_miller<2, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
+      case 3: hipLaunchKernelGGL((k_multi_miller<3, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
+      case 4: hipLaunchKernelGGL((k_multi_miller<4, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
+      default: return BLS381_E_INVALID;
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return BLS381_OK;
+}
+
+int launch_final_exp(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
+  if (n == 0) return BLS381_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  {
+    Timed t(c);
+    hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, in, out, flags, n, c->io_form);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return BLS381_OK;
+}
+
+// RAII device buffers for the host-pointer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// Stages host inputs to the device, runs `body` on device pointers, copies the outputs back.
+template <class Body>
+int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* in2, size_t in2_bytes,
+                 void* out, size_t out_bytes, uint8_t* flags, size_t n, Body body) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  DevBuf d1, d2, dout, dfl;
+  if (in1_bytes) { HIP_TRY(c, hipMalloc(&d1.p, in1_bytes)); HIP_TRY(c, hipMemcpyAsync(d1.p, in1, in1_bytes, hipMemcpyHostToDevice, c->stream)); }
+  if (in2 && in2_bytes) { HIP_TRY(c, hipMalloc(&d2.p, in2_bytes)); HIP_TRY(c, hipMemcpyAsync(d2.p, in2, in2_bytes, hipMemcpyHostToDevice, c->stream)); }
+  HIP_TRY(c, hipMalloc(&dout.p, out_bytes));
+  if (flags) HIP_TRY(c, hipMalloc(&dfl.p, n));
+  int rc = body((const uint64_t*)d1.p, (const uint64_t*)d2.p, (uint64_t*)dout.p, (uint8_t*)dfl.p);
+  if (rc != BLS381_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (flags) HIP_TRY(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BLS381_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bls381_miller_ref_opt_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  return launch_ref_opt(c, g1, g2, out, flags, n);
+}
+
+int bls381_miller_ref_opt_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, g1, n * 144, g2, n * 288, out, n * 576, flags, n,
+                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_ref_opt(c, a, b, o, f, n); });
+}
+
+int bls381_multi_miller_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  return launch_multi<false>(c, g1, g2, k, out, flags, n);
+}
+
+int bls381_multi_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  return launch_multi<true>(c, g1, g2, k, out, flags, n);
+}
+
+int bls381_multi_miller_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, g1, n * k * 96, g2, n * k * 192, out, n * 576, flags, n,
+                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_multi<false>(c, a, b, k, o, f, n); });
+}
+
+int bls381_multi_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, g1, n * k * 96, g2, n * k * 192, out, n * 576, flags, n,
+                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_multi<true>(c, a, b, k, o, f, n); });
+}
+
+int bls381_miller_ate_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  return bls381_multi_miller_batch(c, g1, g2, 1, out, flags, n);
+}
+
+int bls381_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  return bls381_multi_pairing_batch(c, g1, g2, 1, out, flags, n);
+}
+
+int bls381_final_exp_batch_dev(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || (n && (!in || !out))) return BLS381_E_INVALID;
+  return launch_final_exp(c, in, out, flags, n);
+}
+
+int bls381_final_exp_batch(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || (n && (!in || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, in, n * 576, nullptr, 0, out, n * 576, flags, n,
+                      [&](const uint64_t* a, const uint64_t*, uint64_t* o, uint8_t* f) { return launch_final_exp(c, a, o, f, n); });
+}
+
+int bls381_fp_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || op < 0 || op > BLS381_FP_FROM_MONT || (n && (!a || !out))) return BLS381_E_INVALID;
+  if ((op == BLS381_FP_ADD || op == BLS381_FP_SUB || op == BLS381_FP_MUL) && n && !b) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, a, n * 48, b, b ? n * 48 : 0, out, n * 48, nullptr, n,
+                      [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
+                        hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, op, da, db, o, n, c->io_form);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+int bls381_fp12_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || op < 0 || op > BLS381_FP12_CYCLOTOMIC_EXP || (n && (!a || !out))) return BLS381_E_INVALID;
+  if (op == BLS381_FP12_MUL && n && !b) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, a, n * 576, b, b ? n * 576 : 0, out, n * 576, nullptr, n,
+                      [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
+                        hipLaunchKernelGGL(k_fp12_op, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, op, da, db, o, n, c->io_form);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+int bls381_multi_miller_literal(bls381_ctx* c, uint64_t* out, size_t n) {
+  if (!c || (n && !out)) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, nullptr, 0, nullptr, 0, out, n * 576, nullptr, n,
+                      [&](const uint64_t*, const uint64_t*, uint64_t* o, uint8_t*) -> int {
+                        hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, o, n, c->io_form);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+}  // extern "C"

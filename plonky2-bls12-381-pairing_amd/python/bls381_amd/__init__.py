@@ -1,0 +1,207 @@
+"""ctypes binding of libbls381_hip.so (include/bls381_hip.h) -- the Python-side twin of the Rust
+`extern "C"` shim shown in INTEGRATION.md.  It mirrors the reference's two public functions
+
+    optimized_miller_loop(P: G1Projective, Q: G2Projective) -> Fq12      src/miller_loop_native_optimized.rs:81
+    multi_miller_loop(terms: &[(&G1Affine, &G2Affine)]) -> MillerLoopResult   src/miller_loop_native.rs:154
+
+as batch calls over numpy uint64 buffers (6 little-endian limbs per Fp).  There is no CPU fallback: if the
+HIP library or a GPU is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hip.so"))
+
+IO_ARK_MONT, IO_CANONICAL = 0, 1
+OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE = 0, 1, 2
+FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
+FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT = range(8)
+FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP = range(7)
+
+# every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "bls381_create", "bls381_destroy", "bls381_set_option", "bls381_get_option", "bls381_set_stream",
+    "bls381_sync", "bls381_strerror", "bls381_last_hip_error", "bls381_last_kernel_ms",
+    "bls381_miller_ref_opt_batch", "bls381_miller_ref_opt_batch_dev",
+    "bls381_multi_miller_batch", "bls381_multi_miller_batch_dev",
+    "bls381_multi_pairing_batch", "bls381_multi_pairing_batch_dev",
+    "bls381_miller_ate_batch", "bls381_pairing_batch",
+    "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
+    "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
+]
+
+
+class Bls381Error(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise Bls381Error(f"{path} not found: build it with `python __graft_entry__.py` (hipcc, gfx950)")
+    lib = ctypes.CDLL(path)
+    u64p, u8p, sz, vp = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t, ctypes.c_void_p
+    lib.bls381_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.bls381_destroy.argtypes = [vp]
+    lib.bls381_destroy.restype = None
+    lib.bls381_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.bls381_get_option.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    lib.bls381_set_stream.argtypes = [vp, vp]
+    lib.bls381_sync.argtypes = [vp]
+    lib.bls381_strerror.argtypes = [ctypes.c_int]
+    lib.bls381_strerror.restype = ctypes.c_char_p
+    lib.bls381_last_hip_error.argtypes = [vp]
+    lib.bls381_last_kernel_ms.argtypes = [vp]
+    lib.bls381_last_kernel_ms.restype = ctypes.c_float
+    for name in ("bls381_miller_ref_opt_batch", "bls381_miller_ate_batch", "bls381_pairing_batch"):
+        getattr(lib, name).argtypes = [vp, u64p, u64p, u64p, u8p, sz]
+    for name in ("bls381_multi_miller_batch", "bls381_multi_pairing_batch"):
+        getattr(lib, name).argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
+    lib.bls381_final_exp_batch.argtypes = [vp, u64p, u64p, u8p, sz]
+    lib.bls381_fp_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
+    lib.bls381_fp12_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
+    lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
+    # device-pointer twins take raw addresses
+    lib.bls381_miller_ref_opt_batch_dev.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.bls381_multi_miller_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+    lib.bls381_multi_pairing_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+    lib.bls381_final_exp_batch_dev.argtypes = [vp, vp, vp, vp, sz]
+    return lib
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+class Engine:
+    """One context on one GPU (`bls381_ctx`)."""
+
+    def __init__(self, device: int = 0, lib_path: str = LIB_PATH):
+        self.lib = load_library(lib_path)
+        self._ctx = ctypes.c_void_p()
+        rc = self.lib.bls381_create(ctypes.byref(self._ctx), device)
+        if rc != 0:
+            raise Bls381Error(f"bls381_create(device={device}): {self.lib.bls381_strerror(rc).decode()}")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.bls381_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise Bls381Error(f"{what}: {self.lib.bls381_strerror(rc).decode()} (hip error {self.lib.bls381_last_hip_error(self._ctx)})")
+
+    # options ---------------------------------------------------------------
+    def set_option(self, opt, value):
+        self._check(self.lib.bls381_set_option(self._ctx, opt, value), "bls381_set_option")
+
+    def get_option(self, opt):
+        v = ctypes.c_int()
+        self._check(self.lib.bls381_get_option(self._ctx, opt, ctypes.byref(v)), "bls381_get_option")
+        return v.value
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self.lib.bls381_set_stream(self._ctx, ctypes.c_void_p(hip_stream or 0)), "bls381_set_stream")
+
+    def sync(self):
+        self._check(self.lib.bls381_sync(self._ctx), "bls381_sync")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.bls381_last_kernel_ms(self._ctx))
+
+    # host-buffer batch calls ------------------------------------------------
+    def optimized_miller_loop(self, g1_jac, g2_jac):
+        """Batch form of `optimized_miller_loop` (src/miller_loop_native_optimized.rs:81).
+        g1_jac: n*18 u64, g2_jac: n*36 u64 -> (n*72 u64 Fq12, n flag bytes)."""
+        a, pa = _u64(g1_jac)
+        b, pb = _u64(g2_jac)
+        n = a.size // 18
+        assert a.size == n * 18 and b.size == n * 36, "ragged input"
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bls381_miller_ref_opt_batch(self._ctx, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                         flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n),
+                    "bls381_miller_ref_opt_batch")
+        return out, flags
+
+    def _multi(self, fn, name, g1_aff, g2_aff, k):
+        a, pa = _u64(g1_aff)
+        b, pb = _u64(g2_aff)
+        n = a.size // (12 * k)
+        assert a.size == n * 12 * k and b.size == n * 24 * k, "ragged input"
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self._check(fn(self._ctx, pa, pb, k, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                       flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), name)
+        return out, flags
+
+    def multi_miller_loop(self, g1_aff, g2_aff, k=1):
+        """Batch form of `multi_miller_loop` (src/miller_loop_native.rs:154) with the line steps live:
+        n products of k Miller loops each."""
+        return self._multi(self.lib.bls381_multi_miller_batch, "bls381_multi_miller_batch", g1_aff, g2_aff, k)
+
+    def multi_pairing(self, g1_aff, g2_aff, k=1):
+        return self._multi(self.lib.bls381_multi_pairing_batch, "bls381_multi_pairing_batch", g1_aff, g2_aff, k)
+
+    def final_exponentiation(self, f):
+        a, pa = _u64(f)
+        n = a.size // 72
+        out = np.zeros(n * 72, dtype=np.uint64)
+        self._check(self.lib.bls381_final_exp_batch(self._ctx, pa, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), None, n),
+                    "bls381_final_exp_batch")
+        return out
+
+    def fp_op(self, op, a, b=None):
+        a, pa = _u64(a)
+        pb = None
+        if b is not None:
+            b, pb = _u64(b)
+        n = a.size // 6
+        out = np.zeros(n * 6, dtype=np.uint64)
+        self._check(self.lib.bls381_fp_op_batch(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
+                    "bls381_fp_op_batch")
+        return out
+
+    def fp12_op(self, op, a, b=None):
+        a, pa = _u64(a)
+        pb = None
+        if b is not None:
+            b, pb = _u64(b)
+        n = a.size // 72
+        out = np.zeros(n * 72, dtype=np.uint64)
+        self._check(self.lib.bls381_fp12_op_batch(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
+                    "bls381_fp12_op_batch")
+        return out
+
+    def multi_miller_loop_literal(self, n):
+        """What the reference's multi_miller_loop returns today: Fq12::one()."""
+        out = np.zeros(n * 72, dtype=np.uint64)
+        self._check(self.lib.bls381_multi_miller_literal(self._ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
+                    "bls381_multi_miller_literal")
+        return out
+
+    # device-pointer calls (addresses of hipMalloc'ed buffers, e.g. torch tensor .data_ptr()) ----
+    def optimized_miller_loop_dev(self, g1, g2, out, flags, n):
+        self._check(self.lib.bls381_miller_ref_opt_batch_dev(self._ctx, g1, g2, out, flags, n), "bls381_miller_ref_opt_batch_dev")
+
+    def multi_miller_loop_dev(self, g1, g2, k, out, flags, n):
+        self._check(self.lib.bls381_multi_miller_batch_dev(self._ctx, g1, g2, k, out, flags, n), "bls381_multi_miller_batch_dev")
+
+    def multi_pairing_dev(self, g1, g2, k, out, flags, n):
+        self._check(self.lib.bls381_multi_pairing_batch_dev(self._ctx, g1, g2, k, out, flags, n), "bls381_multi_pairing_batch_dev")
+
+    def final_exponentiation_dev(self, f, out, flags, n):
+        self._check(self.lib.bls381_final_exp_batch_dev(self._ctx, f, out, flags, n), "bls381_final_exp_batch_dev")
