@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BLS12-381 pairings/sec (Miller loop + final exponentiation), batch 2^20 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # N > 1
+
+One process per GPU.  A step = one pass of the hot path (bls381_multi_pairing_batch_dev, k = 1) over this rank's
+batch of 2^20 synthetic (G1, G2) pairs already resident in HBM; pairings are independent, so ranks share nothing
+on the data path (weak scaling, total batch = N * 2^20 -- BASELINE.json config "2^23 across 8 GPUs").
+Rank 0 prints ONE JSON line.  `roofline` prices the kernel against HBM as BASELINE.json asks (the path is
+integer-ALU bound, so that fraction is tiny by construction; `int_roofline` prices it against the measured
+v_mad_u64_u32 issue rate).  `cpu_baseline` times the C restatement of the same path (oracle/, a port -- the
+Rust reference cannot be built here) on this box's host cores, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+# algorithmic figures (DESIGN.md "Measurement")
+BYTES_PER_PAIRING = 96 + 192 + 576          # affine G1 + affine G2 in, Fq12 out, each touched once
+FP_MUL_PER_PAIRING = 6916 + 8491            # oracle op count: Miller loop + final exponentiation (oracle/pyref.py __main__)
+MAC_PER_FP_MUL = 288                        # 32x32->64 limb MACs per 381-bit Montgomery multiplication (2 * 12^2)
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s
+INT_MAC_PEAK = 30.3e12                      # measured v_mad_u64_u32 lane-ops/s, profiles/r01_valu_rates_mi355x.txt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16"], default="pairing")
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import torch.distributed as dist
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+
+    import bls381_amd as B
+    from blsutil import synthetic_batch
+
+    n = 1 << args.batch_log2
+    eng = B.Engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.block:
+        eng.set_option(B.OPT_BLOCK_SIZE, args.block)
+
+    k = 3 if args.workload == "groth16" else 1
+    n_units = n // 4 if args.workload == "groth16" else n          # 2^18 proofs x 3 pairs (BASELINE config 4)
+    jac = args.workload == "ref_opt"
+    g1, g2 = synthetic_batch(n_units, seed=0x424C533132333831 + rank, jacobian=jac, k=k, pool=64)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    dout = torch.empty(n_units * 72, dtype=torch.int64, device=dev)
+    dfl = torch.empty(n_units, dtype=torch.uint8, device=dev)
+
+    def step():
+        if args.workload in ("pairing", "groth16"):
+            eng.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), k, dout.data_ptr(), dfl.data_ptr(), n_units)
+        elif args.workload == "miller":
+            eng.multi_miller_loop_dev(d1.data_ptr(), d2.data_ptr(), k, dout.data_ptr(), dfl.data_ptr(), n_units)
+        else:
+            eng.optimized_miller_loop_dev(d1.data_ptr(), d2.data_ptr(), dout.data_ptr(), dfl.data_ptr(), n_units)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(eng.last_kernel_ms())      # HIP events on the launch stream, recorded by the library
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # spot parity inside the bench: the first 64 results of this rank against the oracle (checker only)
+    ok = None
+    if rank == 0 and args.workload == "pairing":
+        from blsutil import COracle
+        exp, _ = COracle().multi(g1[: 64 * 12], g2[: 64 * 24], 1, final_exp=True, threads=8)
+        got = dout[: 64 * 72].cpu().numpy().view(np.uint64)
+        ok = bool(np.array_equal(got, exp))
+        if not ok:
+            raise SystemExit("bench: HIP results differ from the oracle -- number would be invalid")
+
+    if rank == 0:
+        total_units = n_units * world * args.steps
+        value = total_units / elapsed
+        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+        bytes_per_unit = BYTES_PER_PAIRING if k == 1 else (3 * 288 + 576)
+        if jac:
+            bytes_per_unit = 144 + 288 + 576
+        achieved_gbs = bytes_per_unit * n_units / avg_kernel_s / 1e9
+        line = {
+            "metric": "BLS12-381 pairings/sec (Miller+final exp), batch=2^20 per GPU" if args.workload == "pairing"
+                      else "BLS12-381 %s units/sec" % args.workload,
+            "value": value, "unit": "pairings/s" if k == 1 else "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "batch 2^%d full pairings (Miller loop + Fp12 final exponentiation), 1xMI355X per rank"
+                                   % args.batch_log2 if args.workload == "pairing" else args.workload,
+                       "batch_per_gpu": n_units, "pairs_per_unit": k, "io": "arkworks Montgomery 6xu64 AoS, resident in HBM",
+                       "parity_spot_check": ok},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_multi_miller<%d,%s>" % (k, "true" if args.workload in ("pairing", "groth16") else "false"),
+                         "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
+                         "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},
+        }
+        if args.workload == "pairing":
+            macs = FP_MUL_PER_PAIRING * MAC_PER_FP_MUL * n_units / avg_kernel_s
+            line["int_roofline"] = {"bound": "valu_int32_mad", "achieved": macs / 1e12, "peak": INT_MAC_PEAK / 1e12,
+                                    "unit": "T limb-MAC/s", "frac": macs / INT_MAC_PEAK,
+                                    "fp_mul_per_pairing": FP_MUL_PER_PAIRING, "mac_per_fp_mul": MAC_PER_FP_MUL}
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("pairing", "groth16"):
+            from blsutil import COracle
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            sample = 256 * threads
+            cg1, cg2 = synthetic_batch(sample, jacobian=False, k=k, pool=64)
+            orc = COracle()
+            orc.multi(cg1[: 12 * k * threads], cg2[: 24 * k * threads], k, final_exp=True, threads=threads)   # warm
+            c0 = time.perf_counter()
+            orc.multi(cg1, cg2, k, final_exp=True, threads=threads)
+            cdt = time.perf_counter() - c0
+            line["cpu_baseline"] = {"value": sample / cdt, "unit": line["unit"], "cores": threads, "kind": "port",
+                                    "sample": "%d units of the same synthetic workload, C restatement oracle/bls381_oracle.c "
+                                              "(same algorithm; the Rust reference cannot be built here), %.1f s wall" % (sample, cdt)}
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

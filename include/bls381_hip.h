@@ -113,6 +113,12 @@ int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_
 int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
+/* Test surface for the private `optimized_line_function` (src/miller_loop_native_optimized.rs:8-78): all three
+ * branches, including the vertical one (:62-77) the loop never reaches on subgroup inputs.
+ * q1_jac, q2_jac: n x 3 x 2 x 6, p_jac: n x 3 x 6, out_nd: n x (n, d) = n x 2 x 2 x 6. */
+int bls381_debug_line_ref_opt_batch(bls381_ctx* ctx, const uint64_t* q1_jac, const uint64_t* q2_jac,
+                                    const uint64_t* p_jac, uint64_t* out_nd, size_t n);
+
 /* What src/miller_loop_native.rs:154-212 returns TODAY for any input (its line steps are commented out):
  * Fq12::one().  Host-only, here so that a caller can reproduce the literal reference behaviour. */
 int bls381_multi_miller_literal(bls381_ctx* ctx, uint64_t* out_fq12, size_t n);

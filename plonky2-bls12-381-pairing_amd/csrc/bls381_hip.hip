@@ -1,4 +1,4 @@
-// libbls381_hip.so -- HIP kernels (gfx950) and the C ABI of include/bls381_hip.h.
+// libbls381_hip.so -- the C ABI of include/bls381_hip.h (contexts, staging, launches; kernels live in k_*.hip).
 //
 // One pairing per lane; a workgroup is `block` lanes (default one 64-lane wave).  Each entry point cites
 // the reference item it replaces in include/bls381_hip.h.  There is NO host fallback: without a HIP device
@@ -9,103 +9,7 @@
 #include <new>
 
 #include "../../include/bls381_hip.h"
-#include "pairing.cuh"
-
-using namespace bls;
-
-// ------------------------------------------------------------------------------------------ kernels
-#ifndef BLS_MAX_BLOCK
-#define BLS_MAX_BLOCK 256
-#endif
-
-template <bool GENERIC>
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_miller_ref_opt(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
-                 uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const G1Jac p = g1_jac_load(g1 + 18 * i, form);
-  const G2Jac q = g2_jac_load(g2 + 36 * i, form);
-  uint8_t fl = 0;
-  const Fp12R f = miller_ref_opt<GENERIC>(p, q, fl);
-  fp12_store(out + 72 * i, f, form);
-  if (flags) flags[i] = fl;
-}
-
-template <int K, bool FINAL_EXP>
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
-               uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  G1Aff p[K]; G2Aff q[K]; bool skip[K];
-  uint8_t fl = 0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    bool i1, i2;
-    p[j] = g1_aff_load(g1 + 12 * (K * i + j), form, i1);
-    q[j] = g2_aff_load(g2 + 24 * (K * i + j), form, i2);
-    skip[j] = i1 || i2;
-    if (skip[j]) fl |= FLAG_INFINITY;
-  }
-  Fp12R f = miller_ate<K>(p, q, skip);
-  if (FINAL_EXP) f = final_exponentiation(f);
-  fp12_store(out + 72 * i, f, form);
-  if (flags) flags[i] = fl;
-}
-
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_final_exp(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const Fp12R f = fp12_load(in + 72 * i, form);
-  fp12_store(out + 72 * i, final_exponentiation(f), form);
-  if (flags) flags[i] = 0;
-}
-
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (op == BLS381_FP_TO_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_CANONICAL), IO_ARK_MONT); return; }
-  if (op == BLS381_FP_FROM_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_ARK_MONT), IO_CANONICAL); return; }
-  const FpR x = fp_load(a + 6 * i, form);
-  const FpR y = b ? fp_load(b + 6 * i, form) : x;
-  switch (op) {
-    case BLS381_FP_ADD: fp_store(out + 6 * i, add(x, y), form); break;
-    case BLS381_FP_SUB: fp_store(out + 6 * i, sub(x, y), form); break;
-    case BLS381_FP_MUL: fp_store(out + 6 * i, mul(x, y), form); break;
-    case BLS381_FP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
-    case BLS381_FP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
-    case BLS381_FP_NEG: fp_store(out + 6 * i, neg(x), form); break;
-    default: break;
-  }
-}
-
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_fp12_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const Fp12R x = fp12_load(a + 72 * i, form);
-  Fp12R r = x;
-  switch (op) {
-    case BLS381_FP12_MUL: { const Fp12R y = b ? fp12_load(b + 72 * i, form) : x; r = mul(x, y); break; }
-    case BLS381_FP12_SQR: r = sqr(x); break;
-    case BLS381_FP12_INV: r = inv(x); break;
-    case BLS381_FP12_FROBENIUS: r = frobenius(x); break;
-    case BLS381_FP12_CYCLOTOMIC_SQR: r = cyclotomic_square(x); break;
-    case BLS381_FP12_CONJ: r = fit<1, 2>(conj(x)); break;
-    case BLS381_FP12_CYCLOTOMIC_EXP: r = cyclotomic_exp(x); break;
-    default: break;
-  }
-  fp12_store(out + 72 * i, r, form);
-}
-
-__global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fp12_store(out + 72 * i, Fp12R(fp12_one()), form);
-}
+#include "launch.h"
 
 // ------------------------------------------------------------------------------------------ context
 struct bls381_ctx {
@@ -219,8 +123,6 @@ float bls381_last_kernel_ms(const bls381_ctx* c) {
 // ------------------------------------------------------------------------------------------ launches
 namespace {
 
-inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
-
 struct Timed {
   bls381_ctx* c;
   explicit Timed(bls381_ctx* c_) : c(c_) { (void)hipEventRecord(c->ev0, c->stream); }
@@ -232,10 +134,7 @@ int launch_ref_opt(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64
   HIP_TRY(c, hipSetDevice(c->device));
   {
     Timed t(c);
-    if (c->fp2_shortcut)
-      hipLaunchKernelGGL(k_miller_ref_opt<false>, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, g1, g2, out, flags, n, c->io_form);
-    else
-      hipLaunchKernelGGL(k_miller_ref_opt<true>, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, g1, g2, out, flags, n, c->io_form);
+    bls_launch::ref_opt(c->fp2_shortcut != 0, g1, g2, out, flags, n, c->io_form, c->block, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   return BLS381_OK;
@@ -245,16 +144,9 @@ template <bool FE>
 int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  const dim3 g(grid_for(n, c->block)), b(c->block);
   {
     Timed t(c);
-    switch (k) {
-      case 1: hipLaunchKernelGGL((k_multi_miller<1, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
-      case 2: hipLaunchKernelGGL((k_multi_miller<2, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
-      case 3: hipLaunchKernelGGL((k_multi_miller<3, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
-      case 4: hipLaunchKernelGGL((k_multi_miller<4, FE>), g, b, 0, c->stream, g1, g2, out, flags, n, c->io_form); break;
-      default: return BLS381_E_INVALID;
-    }
+    if (!bls_launch::multi(k, FE, g1, g2, out, flags, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
   }
   HIP_TRY(c, hipGetLastError());
   return BLS381_OK;
@@ -265,7 +157,7 @@ int launch_final_exp(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* 
   HIP_TRY(c, hipSetDevice(c->device));
   {
     Timed t(c);
-    hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, in, out, flags, n, c->io_form);
+    bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   return BLS381_OK;
@@ -361,7 +253,7 @@ int bls381_fp_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t*
   if (n == 0) return BLS381_OK;
   return with_staging(c, a, n * 48, b, b ? n * 48 : 0, out, n * 48, nullptr, n,
                       [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
-                        hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, op, da, db, o, n, c->io_form);
+                        bls_launch::fp_op(op, da, db, o, n, c->io_form, c->block, c->stream);
                         HIP_TRY(c, hipGetLastError());
                         return (int)BLS381_OK;
                       });
@@ -373,7 +265,22 @@ int bls381_fp12_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_
   if (n == 0) return BLS381_OK;
   return with_staging(c, a, n * 576, b, b ? n * 576 : 0, out, n * 576, nullptr, n,
                       [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
-                        hipLaunchKernelGGL(k_fp12_op, dim3(grid_for(n, c->block)), dim3(c->block), 0, c->stream, op, da, db, o, n, c->io_form);
+                        bls_launch::fp12_op(op, da, db, o, n, c->io_form, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+int bls381_debug_line_ref_opt_batch(bls381_ctx* c, const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n) {
+  if (!c || (n && (!q1 || !q2 || !p || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DevBuf dp;
+  HIP_TRY(c, hipMalloc(&dp.p, n * 144));
+  HIP_TRY(c, hipMemcpyAsync(dp.p, p, n * 144, hipMemcpyHostToDevice, c->stream));
+  return with_staging(c, q1, n * 288, q2, n * 288, out, n * 192, nullptr, n,
+                      [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
+                        bls_launch::line_ref_opt(da, db, (const uint64_t*)dp.p, o, n, c->io_form, c->block, c->stream);
                         HIP_TRY(c, hipGetLastError());
                         return (int)BLS381_OK;
                       });
@@ -384,7 +291,7 @@ int bls381_multi_miller_literal(bls381_ctx* c, uint64_t* out, size_t n) {
   if (n == 0) return BLS381_OK;
   return with_staging(c, nullptr, 0, nullptr, 0, out, n * 576, nullptr, n,
                       [&](const uint64_t*, const uint64_t*, uint64_t* o, uint8_t*) -> int {
-                        hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, o, n, c->io_form);
+                        bls_launch::fill_one(o, n, c->io_form, c->stream);
                         HIP_TRY(c, hipGetLastError());
                         return (int)BLS381_OK;
                       });

@@ -24,10 +24,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BLS_HD __host__ __device__ __forceinline__
-#define BLS_HD_NOINLINE __host__ __device__ __noinline__
+#define BLS_HD_NOINLINE inline __host__ __device__ __noinline__
 #else
 #define BLS_HD inline __attribute__((always_inline))
-#define BLS_HD_NOINLINE __attribute__((noinline))
+#define BLS_HD_NOINLINE inline __attribute__((noinline))
 #endif
 #define BLS_CONST static constexpr
 

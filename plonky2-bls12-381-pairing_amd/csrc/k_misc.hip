@@ -1,0 +1,103 @@
+// Kernel translation unit of libbls381_hip.so (see bls381_hip.hip for the C ABI).  The library is split into
+// several TUs only to compile them in parallel; each exposes plain host launch functions (launch.h).
+#include <hip/hip_runtime.h>
+#include "../../include/bls381_hip.h"
+#include "pairing.cuh"
+#include "launch.h"
+using namespace bls;
+#ifndef BLS_MAX_BLOCK
+#define BLS_MAX_BLOCK 256
+#endif
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_final_exp(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fp12R f = fp12_load(in + 72 * i, form);
+  fp12_store(out + 72 * i, final_exponentiation(f), form);
+  if (flags) flags[i] = 0;
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op == BLS381_FP_TO_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_CANONICAL), IO_ARK_MONT); return; }
+  if (op == BLS381_FP_FROM_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_ARK_MONT), IO_CANONICAL); return; }
+  const FpR x = fp_load(a + 6 * i, form);
+  const FpR y = b ? fp_load(b + 6 * i, form) : x;
+  switch (op) {
+    case BLS381_FP_ADD: fp_store(out + 6 * i, add(x, y), form); break;
+    case BLS381_FP_SUB: fp_store(out + 6 * i, sub(x, y), form); break;
+    case BLS381_FP_MUL: fp_store(out + 6 * i, mul(x, y), form); break;
+    case BLS381_FP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
+    case BLS381_FP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
+    case BLS381_FP_NEG: fp_store(out + 6 * i, neg(x), form); break;
+    default: break;
+  }
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp12_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fp12R x = fp12_load(a + 72 * i, form);
+  Fp12R r = x;
+  switch (op) {
+    case BLS381_FP12_MUL: { const Fp12R y = b ? fp12_load(b + 72 * i, form) : x; r = mul(x, y); break; }
+    case BLS381_FP12_SQR: r = sqr(x); break;
+    case BLS381_FP12_INV: r = inv(x); break;
+    case BLS381_FP12_FROBENIUS: r = frobenius(x); break;
+    case BLS381_FP12_CYCLOTOMIC_SQR: r = cyclotomic_square(x); break;
+    case BLS381_FP12_CONJ: r = fit<1, 2>(conj(x)); break;
+    case BLS381_FP12_CYCLOTOMIC_EXP: r = cyclotomic_exp(x); break;
+    default: break;
+  }
+  fp12_store(out + 72 * i, r, form);
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_line_ref_opt(const uint64_t* __restrict__ q1, const uint64_t* __restrict__ q2, const uint64_t* __restrict__ p,
+               uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G2Jac a = g2_jac_load(q1 + 36 * i, form), b = g2_jac_load(q2 + 36 * i, form);
+  const G1Jac pt = g1_jac_load(p + 18 * i, form);
+  const LineND l = line_chord(a, b, pt);
+  fp2_store(out + 24 * i, l.n, form);
+  fp2_store(out + 24 * i + 12, l.d, form);
+}
+
+__global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp12_store(out + 72 * i, Fp12R(fp12_one()), form);
+}
+
+namespace bls_launch {
+bool multi(size_t k, bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  switch (k) {
+    case 1: multi_k1(fe, g1, g2, out, flags, n, form, block, s); return true;
+    case 2: multi_k2(fe, g1, g2, out, flags, n, form, block, s); return true;
+    case 3: multi_k3(fe, g1, g2, out, flags, n, form, block, s); return true;
+    case 4: multi_k4(fe, g1, g2, out, flags, n, form, block, s); return true;
+    default: return false;
+  }
+}
+void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, block)), dim3(block), 0, s, in, out, flags, n, form);
+}
+void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);
+}
+void fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_fp12_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);
+}
+void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_line_ref_opt, dim3(grid_for(n, block)), dim3(block), 0, s, q1, q2, p, out, n, form);
+}
+void fill_one(uint64_t* out, size_t n, int form, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, s, out, n, form);
+}
+}  // namespace bls_launch

@@ -1,0 +1,45 @@
+// Kernel translation unit of libbls381_hip.so (see bls381_hip.hip for the C ABI).  The library is split into
+// several TUs only to compile them in parallel; each exposes plain host launch functions (launch.h).
+#include <hip/hip_runtime.h>
+#include "../../include/bls381_hip.h"
+#include "pairing.cuh"
+#include "launch.h"
+using namespace bls;
+#ifndef BLS_MAX_BLOCK
+#define BLS_MAX_BLOCK 256
+#endif
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+#ifndef BLS_K
+#error "compile with -DBLS_K=1..4"
+#endif
+#define BLS_CAT2(a, b) a##b
+#define BLS_CAT(a, b) BLS_CAT2(a, b)
+template <int K, bool FINAL_EXP>
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
+               uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Aff p[K]; G2Aff q[K]; bool skip[K];
+  uint8_t fl = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    bool i1, i2;
+    p[j] = g1_aff_load(g1 + 12 * (K * i + j), form, i1);
+    q[j] = g2_aff_load(g2 + 24 * (K * i + j), form, i2);
+    skip[j] = i1 || i2;
+    if (skip[j]) fl |= FLAG_INFINITY;
+  }
+  Fp12R f = miller_ate<K>(p, q, skip);
+  if (FINAL_EXP) f = final_exponentiation(f);
+  fp12_store(out + 72 * i, f, form);
+  if (flags) flags[i] = fl;
+}
+
+namespace bls_launch {
+void BLS_CAT(multi_k, BLS_K)(bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  if (fe) hipLaunchKernelGGL((k_multi_miller<BLS_K, true>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
+  else hipLaunchKernelGGL((k_multi_miller<BLS_K, false>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
+}
+}  // namespace bls_launch

@@ -1,0 +1,19 @@
+// Host-side launch functions implemented by the kernel translation units (k_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+namespace bls_launch {
+void ref_opt(bool fp2_shortcut, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
+// k in 1..4; returns false for an unsupported k
+bool multi(size_t k, bool final_exp, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
+void multi_k1(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void multi_k2(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void multi_k3(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void multi_k4(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
+void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
+void fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
+void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n, int form, int block, hipStream_t s);
+void fill_one(uint64_t* out, size_t n, int form, hipStream_t s);
+}  // namespace bls_launch

@@ -33,6 +33,7 @@ SYMBOLS = [
     "bls381_miller_ate_batch", "bls381_pairing_batch",
     "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
     "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
+    "bls381_debug_line_ref_opt_batch",
 ]
 
 
@@ -65,6 +66,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_fp_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_fp12_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
+    lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
     # device-pointer twins take raw addresses
     lib.bls381_miller_ref_opt_batch_dev.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.bls381_multi_miller_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
@@ -184,6 +186,17 @@ class Engine:
         out = np.zeros(n * 72, dtype=np.uint64)
         self._check(self.lib.bls381_fp12_op_batch(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
                     "bls381_fp12_op_batch")
+        return out
+
+    def line_ref_opt(self, q1_jac, q2_jac, p_jac):
+        """Test surface for `optimized_line_function` (opt.rs:8-78): returns n x (n, d) Fp2 pairs."""
+        a, pa = _u64(q1_jac)
+        b, pb = _u64(q2_jac)
+        c, pc = _u64(p_jac)
+        n = a.size // 36
+        out = np.zeros(n * 24, dtype=np.uint64)
+        self._check(self.lib.bls381_debug_line_ref_opt_batch(self._ctx, pa, pb, pc, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
+                    "bls381_debug_line_ref_opt_batch")
         return out
 
     def multi_miller_loop_literal(self, n):

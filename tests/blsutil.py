@@ -185,3 +185,87 @@ class HostSim:
                                            _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n))
         assert rc == 0
         return out, flags
+
+    def line_ref_opt(self, q1, q2, p, form=IO_ARK_MONT):
+        n = len(q1) // 36
+        out = np.zeros(n * 24, dtype=np.uint64)
+        rc = self.lib.hostsim_line_ref_opt(form, _ptr(q1), _ptr(q2), _ptr(p), _ptr(out), ctypes.c_size_t(n))
+        assert rc == 0
+        return out
+
+
+# ------------------------------------------------------------------ golden fixtures
+import json  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+def hx(lst):
+    return [int(x, 16) for x in lst]
+
+
+class COracle:
+    """oracle/libbls381_oracle.so (C restatement; checker and CPU baseline)."""
+
+    def __init__(self):
+        so = os.path.join(ROOT, "oracle", "libbls381_oracle.so")
+        src = os.path.join(ROOT, "oracle", "bls381_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        self.lib = ctypes.CDLL(so)
+
+    def miller_ref_opt(self, g1, g2, threads=1):
+        n = len(g1) // 18
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self.lib.oracle_miller_ref_opt_batch(_ptr(g1), _ptr(g2), _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n), threads)
+        return out, flags
+
+    def multi(self, g1, g2, k=1, final_exp=True, threads=1):
+        n = len(g1) // (12 * k)
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.oracle_multi_pairing_batch if final_exp else self.lib.oracle_multi_miller_batch
+        rc = fn(_ptr(g1), _ptr(g2), ctypes.c_size_t(k), _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n), threads)
+        assert rc == 0
+        return out, flags
+
+    def final_exp(self, f, threads=1):
+        n = len(f) // 72
+        out = np.zeros(n * 72, dtype=np.uint64)
+        self.lib.oracle_final_exp_batch(_ptr(f), _ptr(out), ctypes.c_size_t(n), threads)
+        return out
+
+    def fp12_op(self, op, a, b=None):
+        n = len(a) // 72
+        out = np.zeros(n * 72, dtype=np.uint64)
+        assert self.lib.oracle_fp12_op(op, _ptr(a), _ptr(b), _ptr(out), ctypes.c_size_t(n)) == 0
+        return out
+
+    def fp_op(self, op, a, b=None):
+        n = len(a) // 6
+        out = np.zeros(n * 6, dtype=np.uint64)
+        assert self.lib.oracle_fp_op(op, _ptr(a), _ptr(b), _ptr(out), ctypes.c_size_t(n)) == 0
+        return out
+
+
+def synthetic_batch(n, seed=O.SEED, jacobian=False, k=1, pool=64):
+    """Seeded synthetic batch in ABI layout: pool points, element i picks pool entries by a
+    counter-based PRNG; Jacobian inputs get a per-element random representative.  Returns (g1, g2) uint64 arrays.
+    Built by tiling `pool` distinct encoded elements so that 2^20-element batches cost milliseconds."""
+    base = random_pairs(pool * k, seed, jacobian=jacobian)
+    if jacobian:
+        g1 = enc_fps([c for P, Q in base for c in flat_g1_jac(P)])
+        g2 = enc_fps([c for P, Q in base for c in flat_g2_jac(Q)])
+        w1, w2 = 18, 36
+    else:
+        g1 = enc_fps([c for P, Q in base for c in flat_g1_aff(P)])
+        g2 = enc_fps([c for P, Q in base for c in flat_g2_aff(Q)])
+        w1, w2 = 12 * k, 24 * k
+    reps = (n + pool - 1) // pool
+    return np.tile(g1, reps)[: n * w1].copy(), np.tile(g2, reps)[: n * w2].copy()

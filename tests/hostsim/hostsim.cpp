@@ -132,6 +132,17 @@ int hostsim_miller_ref_opt(int form, int generic, const uint64_t* g1, const uint
   return 0;
 }
 
+int hostsim_line_ref_opt(int form, const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const G2Jac a = g2_jac_load(q1 + 36 * i, form), b = g2_jac_load(q2 + 36 * i, form);
+    const G1Jac pt = g1_jac_load(p + 18 * i, form);
+    const LineND l = line_chord(a, b, pt);
+    fp2_store(out + 24 * i, l.n, form);
+    fp2_store(out + 24 * i + 12, l.d, form);
+  }
+  return 0;
+}
+
 }  // extern "C"
 
 template <int K>

@@ -1,0 +1,202 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libbls381_hip.so via ctypes), against the
+oracle and the committed golden fixtures -- bit-exact (integer arithmetic).  `pytest -m gpu` on an MI355X."""
+import random
+
+import numpy as np
+import pytest
+
+from blsutil import (O, enc_fps, dec_fps, enc_fp12s, dec_fp12s, load_golden, hx, rand_fp, rand_fp12, random_pairs,
+                     flat_g1_jac, flat_g2_jac, flat_g1_aff, flat_g2_aff, synthetic_batch, IO_ARK_MONT, IO_CANONICAL)
+import bls381_amd as B
+
+pytestmark = pytest.mark.gpu
+
+
+def _fp12(h):
+    return O.fp12_unflatten(hx(h))
+
+
+def test_fp_ops_and_kat3_montgomery_conversion(engine):
+    rng = random.Random(7)
+    xs = [rand_fp(rng) for _ in range(300)] + [0, 1, O.P - 1, O.P - 1]
+    ys = [rand_fp(rng) for _ in range(300)] + [5, O.P - 1, O.P - 1, 1]
+    a, b = enc_fps(xs), enc_fps(ys)
+    assert dec_fps(engine.fp_op(B.FP_ADD, a, b)) == [(x + y) % O.P for x, y in zip(xs, ys)]
+    assert dec_fps(engine.fp_op(B.FP_SUB, a, b)) == [(x - y) % O.P for x, y in zip(xs, ys)]
+    assert dec_fps(engine.fp_op(B.FP_MUL, a, b)) == [(x * y) % O.P for x, y in zip(xs, ys)]
+    assert dec_fps(engine.fp_op(B.FP_SQR, a)) == [(x * x) % O.P for x in xs]
+    assert dec_fps(engine.fp_op(B.FP_NEG, a)) == [(-x) % O.P for x in xs]
+    assert dec_fps(engine.fp_op(B.FP_INV, a)) == [pow(x, O.P - 2, O.P) for x in xs]
+    # KAT-3: the reference's hard-coded generator limbs are to_mont(canonical generator coordinates)
+    k = load_golden("reference_kats.json")["kat3_generators_montgomery"]
+    gen = [O.G1_GEN[0], O.G1_GEN[1], *O.G2_GEN[0], *O.G2_GEN[1]]
+    mont = engine.fp_op(B.FP_TO_MONT, enc_fps(gen, IO_CANONICAL)).reshape(-1, 6)
+    got = [sum(int(l) << (64 * i) for i, l in enumerate(row)) for row in mont]
+    assert got == [k["g1_x"], k["g1_y"], *k["g2_x"], *k["g2_y"]]
+    assert np.array_equal(engine.fp_op(B.FP_FROM_MONT, mont.reshape(-1)), enc_fps(gen, IO_CANONICAL))
+
+
+def test_kat1_kat2_on_device(engine):
+    K = load_golden("reference_kats.json")
+    engine.set_option(B.OPT_IO_FORM, IO_CANONICAL)     # the reference feeds raw limbs to a canonical-limb type
+    try:
+        for name, op in (("kat1_fp2_add", B.FP_ADD), ("kat2_fp2_sub", B.FP_SUB)):
+            k = K[name]
+            out = dec_fps(engine.fp_op(op, enc_fps(k["a"], IO_CANONICAL), enc_fps(k["b"], IO_CANONICAL)), IO_CANONICAL)
+            assert out == k["c"], name
+    finally:
+        engine.set_option(B.OPT_IO_FORM, IO_ARK_MONT)
+
+
+def test_tower_ops_golden(engine):
+    cases = load_golden("tower_ops.json")["cases"]
+    X = enc_fp12s([_fp12(c["x"]) for c in cases]); Y = enc_fp12s([_fp12(c["y"]) for c in cases])
+    for op, key in ((B.FP12_MUL, "mul"), (B.FP12_SQR, "sqr"), (B.FP12_INV, "inv"), (B.FP12_FROBENIUS, "frobenius"),
+                    (B.FP12_CYCLOTOMIC_SQR, "cyclotomic_square"), (B.FP12_CONJ, "conj")):
+        assert dec_fp12s(engine.fp12_op(op, X, Y)) == [_fp12(c[key]) for c in cases], key
+    assert dec_fp12s(engine.final_exponentiation(X)) == [_fp12(c["final_exp"]) for c in cases]
+    assert dec_fp12s(engine.fp12_op(B.FP12_CYCLOTOMIC_EXP, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
+
+
+def test_tower_identities_kat5(engine):
+    """x^2 == x*x and (a+b) c^2 == c^2 a + c^2 b on device (the reference's test_fq12_arithmetic shape)."""
+    rng = random.Random(55)
+    n = 64
+    xs = [rand_fp12(rng) for _ in range(n)]; ys = [rand_fp12(rng) for _ in range(n)]
+    X, Y = enc_fp12s(xs), enc_fp12s(ys)
+    assert np.array_equal(engine.fp12_op(B.FP12_SQR, X), engine.fp12_op(B.FP12_MUL, X, X))
+    inv = engine.fp12_op(B.FP12_INV, X)
+    one = enc_fp12s([O.FP12_ONE] * n)
+    assert np.array_equal(engine.fp12_op(B.FP12_MUL, X, inv), one)
+    assert dec_fp12s(engine.fp12_op(B.FP12_MUL, X, Y))[:8] == [O.fp12_mul(x, y) for x, y in zip(xs[:8], ys[:8])]
+
+
+@pytest.mark.parametrize("shortcut", [0, 1])
+def test_mode_a_golden(engine, shortcut):
+    cases = load_golden("mode_a.json")["cases"]
+    g1 = enc_fps([v for c in cases for v in hx(c["g1_jac"])]); g2 = enc_fps([v for c in cases for v in hx(c["g2_jac"])])
+    engine.set_option(B.OPT_REF_OPT_FP2_SHORTCUT, shortcut)
+    try:
+        out, fl = engine.optimized_miller_loop(g1, g2)
+    finally:
+        engine.set_option(B.OPT_REF_OPT_FP2_SHORTCUT, 0)
+    assert dec_fp12s(out) == [_fp12(c["out"]) for c in cases]
+    assert list(fl) == [c["flags"] for c in cases]
+    # only the c0.c0 slot is populated
+    o = out.reshape(len(cases), 12, 6)
+    assert not o[:, 2:, :].any()
+
+
+def test_mode_a_vs_c_oracle_batch(engine, coracle):
+    n = 1024 + 37                                  # ragged against every block size
+    g1, g2 = synthetic_batch(n, seed=4242, jacobian=True, pool=128)
+    exp, efl = coracle.miller_ref_opt(g1, g2, threads=16)
+    for block in (64, 256):
+        engine.set_option(B.OPT_BLOCK_SIZE, block)
+        out, fl = engine.optimized_miller_loop(g1, g2)
+        assert np.array_equal(out, exp) and np.array_equal(fl, efl), block
+    engine.set_option(B.OPT_BLOCK_SIZE, 64)
+    engine.set_option(B.OPT_REF_OPT_FP2_SHORTCUT, 1)
+    out, fl = engine.optimized_miller_loop(g1, g2)
+    engine.set_option(B.OPT_REF_OPT_FP2_SHORTCUT, 0)
+    assert np.array_equal(out, exp)
+
+
+def test_line_function_three_branches(engine):
+    cases = load_golden("line_fn.json")["cases"]
+    q1 = enc_fps([v for c in cases for v in hx(c["q1"])]); q2 = enc_fps([v for c in cases for v in hx(c["q2"])])
+    p = enc_fps([v for c in cases for v in hx(c["p"])])
+    assert dec_fps(engine.line_ref_opt(q1, q2, p)) == [v for c in cases for v in hx(c["n"]) + hx(c["d"])]
+
+
+def test_mode_b_golden(engine):
+    g = load_golden("mode_b.json")
+    s = g["single"]
+    g1 = enc_fps([v for c in s for v in hx(c["g1"])]); g2 = enc_fps([v for c in s for v in hx(c["g2"])])
+    out, fl = engine.multi_miller_loop(g1, g2, 1)
+    assert dec_fp12s(out) == [_fp12(c["miller"]) for c in s] and list(fl) == [c["flags"] for c in s]
+    out, fl = engine.multi_pairing(g1, g2, 1)
+    assert dec_fp12s(out) == [_fp12(c["pairing"]) for c in s] and list(fl) == [c["flags"] for c in s]
+    m = g["multi"]
+    g1 = enc_fps([v for c in m for p in c["g1"] for v in hx(p)]); g2 = enc_fps([v for c in m for q in c["g2"] for v in hx(q)])
+    out, fl = engine.multi_pairing(g1, g2, 3)
+    assert dec_fp12s(out) == [_fp12(c["pairing"]) for c in m] and list(fl) == [c["flags"] for c in m]
+    out, fl = engine.multi_miller_loop(g1, g2, 3)
+    assert dec_fp12s(out) == [_fp12(c["miller"]) for c in m]
+    # miller then separate final exponentiation == fused pairing
+    assert np.array_equal(engine.final_exponentiation(out), engine.multi_pairing(g1, g2, 3)[0])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_mode_b_vs_c_oracle_batch(engine, coracle, k):
+    n = 300 + k
+    g1, g2 = synthetic_batch(n, seed=9000 + k, jacobian=False, k=k, pool=50)
+    exp, efl = coracle.multi(g1, g2, k, final_exp=True, threads=16)
+    out, fl = engine.multi_pairing(g1, g2, k)
+    assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+    expm, _ = coracle.multi(g1, g2, k, final_exp=False, threads=16)
+    outm, _ = engine.multi_miller_loop(g1, g2, k)
+    assert np.array_equal(outm, expm)
+
+
+def test_bilinearity_on_device(engine):
+    """e(aP, bQ) == e(P, Q)^(ab) == e(abP, Q), computed on the GPU."""
+    a, b = 11, 23
+    P, Q = O.G1_GEN, O.G2_GEN
+    ins = [(O.g1_mul(a), O.g2_mul(b)), (O.g1_mul(a * b), Q), (P, O.g2_mul(a * b)), (P, Q)]
+    g1 = enc_fps([c for p, q in ins for c in flat_g1_aff(p)]); g2 = enc_fps([c for p, q in ins for c in flat_g2_aff(q)])
+    out, _ = engine.multi_pairing(g1, g2, 1)
+    e = dec_fp12s(out)
+    assert e[0] == e[1] == e[2] == O.fp12_pow(e[3], a * b)
+    assert not O.fp12_is_one(e[3]) and O.fp12_is_one(O.fp12_pow(e[3], O.R_ORDER))
+
+
+def test_canonical_io_and_empty_and_errors(engine):
+    c = load_golden("mode_b.json")["single"][0]
+    engine.set_option(B.OPT_IO_FORM, IO_CANONICAL)
+    try:
+        out, _ = engine.multi_pairing(enc_fps(hx(c["g1"]), IO_CANONICAL), enc_fps(hx(c["g2"]), IO_CANONICAL), 1)
+        assert dec_fp12s(out, IO_CANONICAL) == [_fp12(c["pairing"])]
+    finally:
+        engine.set_option(B.OPT_IO_FORM, IO_ARK_MONT)
+    out, fl = engine.multi_pairing(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 1)   # empty batch
+    assert out.size == 0 and fl.size == 0
+    out, fl = engine.optimized_miller_loop(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64))
+    assert out.size == 0
+    with pytest.raises(B.Bls381Error):
+        engine.multi_pairing(np.zeros(12 * 5, dtype=np.uint64), np.zeros(24 * 5, dtype=np.uint64), 5)   # k out of range
+    with pytest.raises(B.Bls381Error):
+        engine.set_option(B.OPT_BLOCK_SIZE, 100)
+    with pytest.raises(AssertionError):
+        engine.multi_pairing(np.zeros(13, dtype=np.uint64), np.zeros(24, dtype=np.uint64), 1)           # ragged
+    one = dec_fp12s(engine.multi_miller_loop_literal(3))
+    assert all(O.fp12_is_one(x) for x in one)                                                            # config 0 / SURVEY F4
+
+
+def test_full_size_batch_properties(engine, coracle):
+    """BASELINE size (2^20 full pairings): the batch tiles a 64-element pool, so (1) the first period must equal the
+    oracle and (2) every later period must equal the first, bit for bit -- a checksum of checksums over 604 MB."""
+    n = 1 << 20
+    pool = 64
+    g1, g2 = synthetic_batch(n, jacobian=False, pool=pool)
+    out, fl = engine.multi_pairing(g1, g2, 1)
+    o = out.reshape(n // pool, pool * 72)
+    exp, _ = coracle.multi(g1[: pool * 12], g2[: pool * 24], 1, final_exp=True, threads=16)
+    assert np.array_equal(o[0], exp)
+    assert (o == o[0]).all()
+    assert not fl.any()
+
+
+def test_mode_a_64k_batch_properties(engine, coracle):
+    """configs[1] size (2^16 Miller loops, Mode A)."""
+    n = 1 << 16
+    pool = 64
+    g1, g2 = synthetic_batch(n, jacobian=True, pool=pool)
+    engine.set_option(B.OPT_REF_OPT_FP2_SHORTCUT, 1)
+    try:
+        out, fl = engine.optimized_miller_loop(g1, g2)
+    finally:
+        engine.set_option(B.OPT_REF_OPT_FP2_SHORTCUT, 0)
+    o = out.reshape(n // pool, pool * 72)
+    exp, _ = coracle.miller_ref_opt(g1[: pool * 18], g2[: pool * 36], threads=16)
+    assert np.array_equal(o[0], exp) and (o == o[0]).all() and not fl.any()

@@ -1,0 +1,107 @@
+"""Device algorithms compiled for the host (tests/hostsim) against the golden fixtures and the oracle, with
+every static limb/value bound of the lazy-reduction types verified at run time (BLS_BOUND_CHECK).
+This is how kernel logic is validated in the GPU-less container; the GPU parity tests proper are test_gpu_*.py."""
+import random
+
+import numpy as np
+from blsutil import (O, enc_fps, dec_fps, enc_fp12s, dec_fp12s, load_golden, hx, rand_fp, rand_fp2, rand_fp12,
+                     random_pairs, flat_g1_jac, flat_g2_jac, IO_ARK_MONT, IO_CANONICAL)
+
+
+def _fp12(h):
+    return O.fp12_unflatten(hx(h))
+
+
+def test_fp_ops_both_encodings(hostsim):
+    rng = random.Random(7)
+    xs = [rand_fp(rng) for _ in range(24)] + [0, 1, O.P - 1, O.P - 1]
+    ys = [rand_fp(rng) for _ in range(24)] + [5, O.P - 1, O.P - 1, 1]
+    for form in (IO_ARK_MONT, IO_CANONICAL):
+        a, b = enc_fps(xs, form), enc_fps(ys, form)
+        assert dec_fps(hostsim.fp_op(0, a, b, form), form) == [(x + y) % O.P for x, y in zip(xs, ys)]
+        assert dec_fps(hostsim.fp_op(1, a, b, form), form) == [(x - y) % O.P for x, y in zip(xs, ys)]
+        assert dec_fps(hostsim.fp_op(2, a, b, form), form) == [(x * y) % O.P for x, y in zip(xs, ys)]
+        assert dec_fps(hostsim.fp_op(3, a, None, form), form) == [(x * x) % O.P for x in xs]
+        assert dec_fps(hostsim.fp_op(5, a, None, form), form) == [(-x) % O.P for x in xs]
+        assert dec_fps(hostsim.fp_op(4, a, None, form), form) == [pow(x, O.P - 2, O.P) for x in xs]
+    # to/from Montgomery (KAT-3 shape): canonical -> ark form and back
+    can = enc_fps(xs, IO_CANONICAL)
+    mont = hostsim.fp_op(6, can)
+    assert np.array_equal(mont, enc_fps(xs, IO_ARK_MONT))
+    assert np.array_equal(hostsim.fp_op(7, mont), can)
+
+
+def test_unreduced_inputs_are_reduced(hostsim):
+    """Inputs >= p (any 384-bit pattern) are accepted and reduced, like a `from_biguint`-style load."""
+    vals = [O.P, O.P + 1, 2 ** 384 - 1, 2 * O.P + 5]
+    a = np.array([(v >> (64 * i)) & (2 ** 64 - 1) for v in vals for i in range(6)], dtype=np.uint64)
+    one = enc_fps([1] * len(vals), IO_CANONICAL)
+    out = dec_fps(hostsim.fp_op(2, a, one, IO_CANONICAL), IO_CANONICAL)
+    assert out == [v % O.P for v in vals]
+
+
+def test_fp2_ops(hostsim):
+    rng = random.Random(8)
+    a2 = [rand_fp2(rng) for _ in range(8)] + [(0, 0), (1, 0), (0, 1)]
+    b2 = [rand_fp2(rng) for _ in range(8)] + [(5, 7), (O.P - 1, 3), (O.P - 1, O.P - 1)]
+    A = enc_fps([c for v in a2 for c in v]); B = enc_fps([c for v in b2 for c in v])
+    pair = lambda r: [(r[2 * i], r[2 * i + 1]) for i in range(len(r) // 2)]
+    assert pair(dec_fps(hostsim.fp2_op(0, A, B))) == [O.fp2_mul(x, y) for x, y in zip(a2, b2)]
+    assert pair(dec_fps(hostsim.fp2_op(1, A))) == [O.fp2_sqr(x) for x in a2]
+    assert pair(dec_fps(hostsim.fp2_op(3, A))) == [O.fp2_mul_by_nonresidue(x) for x in a2]
+    assert pair(dec_fps(hostsim.fp2_op(4, A))) == [O.fp2_conj(x) for x in a2]
+    inv = pair(dec_fps(hostsim.fp2_op(2, A)))
+    assert inv == [O.fp2_inv(x) or (0, 0) for x in a2]
+
+
+def test_tower_golden(hostsim):
+    cases = load_golden("tower_ops.json")["cases"]
+    X = enc_fp12s([_fp12(c["x"]) for c in cases]); Y = enc_fp12s([_fp12(c["y"]) for c in cases])
+    for op, key in ((0, "mul"), (1, "sqr"), (2, "inv"), (3, "frobenius"), (4, "cyclotomic_square"), (5, "conj"), (7, "final_exp")):
+        assert dec_fp12s(hostsim.fp12_op(op, X, Y)) == [_fp12(c[key]) for c in cases], key
+    assert dec_fp12s(hostsim.fp12_op(6, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
+
+
+def test_mode_a_golden_both_variants(hostsim):
+    cases = load_golden("mode_a.json")["cases"]
+    g1 = enc_fps([v for c in cases for v in hx(c["g1_jac"])])
+    g2 = enc_fps([v for c in cases for v in hx(c["g2_jac"])])
+    for generic in (False, True):
+        out, fl = hostsim.miller_ref_opt(g1, g2, generic=generic)
+        assert dec_fp12s(out) == [_fp12(c["out"]) for c in cases], generic
+        assert list(fl) == [c["flags"] for c in cases]
+
+
+def test_line_function_three_branches(hostsim):
+    cases = load_golden("line_fn.json")["cases"]
+    assert sorted(c["branch"] for c in cases) == ["A", "T", "V"]
+    q1 = enc_fps([v for c in cases for v in hx(c["q1"])]); q2 = enc_fps([v for c in cases for v in hx(c["q2"])])
+    p = enc_fps([v for c in cases for v in hx(c["p"])])
+    out = dec_fps(hostsim.line_ref_opt(q1, q2, p))
+    exp = [v for c in cases for v in hx(c["n"]) + hx(c["d"])]
+    assert out == exp
+
+
+def test_mode_b_golden(hostsim):
+    g = load_golden("mode_b.json")
+    s = g["single"]
+    g1 = enc_fps([v for c in s for v in hx(c["g1"])]); g2 = enc_fps([v for c in s for v in hx(c["g2"])])
+    out, fl = hostsim.multi_miller(g1, g2, 1, final_exp=False)
+    assert dec_fp12s(out) == [_fp12(c["miller"]) for c in s] and list(fl) == [c["flags"] for c in s]
+    out, fl = hostsim.multi_miller(g1, g2, 1, final_exp=True)
+    assert dec_fp12s(out) == [_fp12(c["pairing"]) for c in s]
+    m = g["multi"]
+    g1 = enc_fps([v for c in m for p in c["g1"] for v in hx(p)]); g2 = enc_fps([v for c in m for q in c["g2"] for v in hx(q)])
+    out, fl = hostsim.multi_miller(g1, g2, 3, final_exp=True)
+    assert dec_fp12s(out) == [_fp12(c["pairing"]) for c in m] and list(fl) == [c["flags"] for c in m]
+
+
+def test_canonical_io_form(hostsim):
+    c = load_golden("mode_a.json")["cases"][0]
+    g1 = enc_fps(hx(c["g1_jac"]), IO_CANONICAL); g2 = enc_fps(hx(c["g2_jac"]), IO_CANONICAL)
+    out, _ = hostsim.miller_ref_opt(g1, g2, generic=False, form=IO_CANONICAL)
+    assert dec_fp12s(out, IO_CANONICAL) == [_fp12(c["out"])]
+
+
+def test_bound_checks_ran(hostsim):
+    assert hostsim.lib.hostsim_bound_checks() > 100000

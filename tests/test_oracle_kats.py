@@ -1,0 +1,106 @@
+"""Pins the oracle (oracle/pyref.py) against every known answer the reference's own files hold for this
+path (numbers extracted by tools/extract_reference_kats.py), and against
+the algebraic invariants that stand in for the Miller-loop vectors the reference lacks."""
+from blsutil import O, load_golden, hx
+
+K = load_golden("reference_kats.json")
+
+
+def test_kat6_p_and_loop_constants():
+    d = K["kat6_p_u32_digits"]["digits_le"]
+    assert sum(x << (32 * i) for i, x in enumerate(d)) == O.P
+    assert int(K["kat6_scalar_field"]["p_decimal"]) == O.P
+    assert int(K["kat6_scalar_field"]["r_decimal"]) == O.R_ORDER
+    assert K["kat6_bls_x"]["bls_x"] == O.BLS_X and K["kat6_bls_x"]["negative"] is True
+    bits = K["kat6_pseudo_binary_encoding"]["bits"]
+    assert bits == O.PSEUDO_BINARY_ENCODING and sum(bits) == 6
+    assert [i for i, b in enumerate(bits) if b] == [16, 48, 57, 60, 62, 63]
+    assert (O.P ** 12 - 1) % O.R_ORDER == 0 and O.P % 4 == 3
+
+
+def test_kat1_kat2_fp2_add_sub():
+    for name, fn in (("kat1_fp2_add", O.fp2_add), ("kat2_fp2_sub", O.fp2_sub)):
+        k = K[name]
+        a, b, c = tuple(k["a"]), tuple(k["b"]), tuple(k["c"])
+        assert fn(a, b) == c, name
+
+
+def test_kat3_generators_are_montgomery_forms():
+    k = K["kat3_generators_montgomery"]
+    assert O.to_mont(O.G1_GEN[0]) == k["g1_x"] and O.to_mont(O.G1_GEN[1]) == k["g1_y"]
+    assert [O.to_mont(c) for c in O.G2_GEN[0]] == k["g2_x"]
+    assert [O.to_mont(c) for c in O.G2_GEN[1]] == k["g2_y"]
+    assert O.g1_on_curve(O.G1_GEN) and O.g2_on_curve(O.G2_GEN)
+    # limb codec round trip
+    assert O.fp_from_limbs(O.fp_to_limbs(O.G1_GEN[0])) == O.G1_GEN[0]
+
+
+def test_kat4_frobenius_constants():
+    k = K["kat4_frobenius_montgomery"]
+    assert O.FROB6_C1[0] == 0 and O.to_mont(O.FROB6_C1[1]) == k["frob6_c1_c1"]
+    assert O.FROB6_C2[1] == 0 and O.to_mont(O.FROB6_C2[0]) == k["frob6_c2_c0"]
+    assert [O.to_mont(c) for c in O.FROB12_C1] == k["frob12_c1"]
+
+
+def test_kat5_tower_identities_and_myfq12_convention():
+    import random
+    rng = random.Random(5)
+    for _ in range(3):
+        x = O.fp12_unflatten([rng.randrange(O.P) for _ in range(12)])
+        a = O.fp12_unflatten([rng.randrange(O.P) for _ in range(12)])
+        b = O.fp12_unflatten([rng.randrange(O.P) for _ in range(12)])
+        assert O.fp12_sqr(x) == O.fp12_mul(x, x)                                    # x^2 == x*x
+        c2 = O.fp12_sqr(x)
+        ab = (O.fp6_add(a[0], b[0]), O.fp6_add(a[1], b[1]))
+        lhs = O.fp12_mul(ab, c2)
+        r1, r2 = O.fp12_mul(c2, a), O.fp12_mul(c2, b)
+        assert lhs == (O.fp6_add(r1[0], r2[0]), O.fp6_add(r1[1], r2[1]))            # (a+b) c^2 == c^2 a + c^2 b
+        # src/fields/helpers.rs:248-267 (test_myfq12): flat schoolbook product with w^6 = 1 + u
+        assert O.myfq12_mul(O.fp12_to_myfq12(a), O.fp12_to_myfq12(b)) == O.fp12_to_myfq12(O.fp12_mul(a, b))
+        assert O.fp12_frobenius(x) == O.fp12_pow(x, O.P)
+        assert O.fp12_is_one(O.fp12_mul(x, O.fp12_inv(x)))
+
+
+def test_mode_a_generator_matches_survey_known_answer():
+    # SURVEY.md App. B.3 (derived independently by the surveyor's scratch model)
+    out, fl = O.optimized_miller_loop((O.G1_GEN[0], O.G1_GEN[1], 1), (O.G2_GEN[0], O.G2_GEN[1], O.FP2_ONE))
+    assert fl == 0
+    flat = O.fp12_flatten(out)
+    assert flat[0] == 0x0E55CD9A3D95A195EC346327D178B2FFC9F64BA2549836A96ABFDA2F36D30A7E5EC79CCD733A41654F7A4AC5734442EB
+    assert flat[1] == 0x083760D368BA995315D0DD4F05CDAA088AAA6AFBBB73F38B01F17807D4AB16AFA527D7BE455E0F9D9DC471E05C804F57
+    assert all(v == 0 for v in flat[2:])
+    tr = []
+    O.optimized_miller_loop((O.G1_GEN[0], O.G1_GEN[1], 1), (O.G2_GEN[0], O.G2_GEN[1], O.FP2_ONE), False, tr)
+    assert tr.count("T") == 64 and tr.count("A") == 6 and "V" not in tr
+
+
+def test_mode_a_generic_equals_fp2_shortcut():
+    g = load_golden("mode_a.json")["cases"][1]
+    P = tuple(hx(g["g1_jac"])); q = hx(g["g2_jac"]); Q = ((q[0], q[1]), (q[2], q[3]), (q[4], q[5]))
+    a, _ = O.optimized_miller_loop(P, Q, True)
+    b, _ = O.optimized_miller_loop(P, Q, False)
+    assert a == b and O.fp12_flatten(a) == hx(g["out"])
+
+
+def test_mode_b_invariants():
+    e = O.pairing(O.G1_GEN, O.G2_GEN)
+    assert not O.fp12_is_one(e) and O.fp12_is_one(O.fp12_pow(e, O.R_ORDER))
+    a, b = 7, 13
+    assert O.pairing(O.g1_mul(a), O.g2_mul(b)) == O.fp12_pow(e, a * b)               # bilinearity
+    qn = (O.G2_GEN[0], O.fp2_neg(O.G2_GEN[1]))
+    assert O.fp12_is_one(O.fp12_mul(O.pairing(O.G1_GEN, qn), e))                     # e(P,-Q) e(P,Q) = 1
+    pa, qb = O.g1_mul(a), O.g2_mul(b)
+    assert O.multi_miller_loop([(pa, qb), (O.G1_GEN, O.G2_GEN)]) == O.fp12_mul(O.miller_loop(pa, qb), O.miller_loop(O.G1_GEN, O.G2_GEN))
+    assert len(O.g2_prepare(O.G2_GEN)) == 68                                         # src/miller_loop_target.rs:69
+    assert O.fp12_is_one(O.multi_miller_loop_literal([(O.G1_GEN, O.G2_GEN)]))
+
+
+def test_golden_files_reproduce():
+    """The committed fixtures are what the oracle computes today (guards against silent oracle drift)."""
+    for c in load_golden("mode_a.json")["cases"][:4]:
+        P = tuple(hx(c["g1_jac"])); q = hx(c["g2_jac"]); Q = ((q[0], q[1]), (q[2], q[3]), (q[4], q[5]))
+        out, fl = O.optimized_miller_loop(P, Q, False)
+        assert O.fp12_flatten(out) == hx(c["out"]) and fl == c["flags"]
+    for c in load_golden("mode_b.json")["single"][:3]:
+        P = tuple(hx(c["g1"])); q = hx(c["g2"]); Q = ((q[0], q[1]), (q[2], q[3]))
+        assert O.fp12_flatten(O.pairing(P, Q)) == hx(c["pairing"])
