@@ -1,0 +1,172 @@
+// Fp2 = Fp[u]/(u^2+1), LANE-PAIR backend (gfx950): one Fp2 element is split across two adjacent lanes of a
+// wave -- the even lane holds c0, the odd lane holds c1 -- so one pairing occupies a lane pair and a 64-lane wave
+// carries 32 pairings.
+//
+// Why: the whole Miller-loop / final-exponentiation state of one pairing is ~340 Fp-sized registers in the serial
+// layout, more than a lane owns even at one wave per SIMD (512 VGPRs); it spills to scratch and the kernel ends
+// up bound by HBM traffic (profiles/r01_v1_baseline).  Splitting Fp2 halves the per-lane state and the per-lane code
+// (each lane executes ONE fused multiply-pair per Fp2 product instead of two), so the state stays in registers.
+//
+// An Fp2 product (a0 + a1 u)(b0 + b1 u) maps onto the pair with no idle lane:
+//     even lane:  c0 = a0*b0 + (-a1)*b1         odd lane:  c1 = a0*b1 + a1*b0
+// i.e. both lanes run  mul2(a0, b_self, +-a1, b_other)  after fetching the partner's coefficients with two DPP
+// quad_perm:[1,0,3,2] moves per limb (full-rate VALU, no LDS).  Squaring is (a0+a1)(a0-a1) on the even lane and
+// (2 a0) a1 on the odd lane: one single-product multiplication each.
+//
+// Formulas: src/fields_as_trees/fq2_target_tree.rs:54-142 (reference).  Same API as fp2_serial.cuh.
+#pragma once
+#include "fp.cuh"
+
+namespace bls {
+
+constexpr int LANES_PER_ELEM = 2;
+
+// 0 on the lane holding c0, 1 on the lane holding c1
+BLS_HD int lane_part() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)(threadIdx.x & 1u);
+#else
+  return 0;
+#endif
+}
+
+// value held by the partner lane (lane ^ 1)
+BLS_HD uint32_t dpp_swap(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+#else
+  return x;   // host pass only type-checks this backend; the host simulation uses fp2_serial.cuh
+#endif
+}
+template <int L, int V>
+BLS_HD Fp<L, V> swap(const Fp<L, V>& a) {
+  Fp<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = dpp_swap(a.l[i]);
+  return r;
+}
+
+template <int L, int V>
+struct Fp2 {
+  Fp<L, V> v;                          // this lane's coefficient
+  Fp2() = default;
+  BLS_HD explicit Fp2(const Fp<L, V>& a) : v(a) {}
+  template <int L2, int V2>
+  BLS_HD Fp2(const Fp2<L2, V2>& o) : v(o.v) {}
+};
+using Fp2R = Fp2<1, 2>;
+
+template <int L, int V> BLS_HD Fp2<L, V> wrap2(const Fp<L, V>& a) { return Fp2<L, V>(a); }
+
+// select between two Fp of different bounds (result carries the looser bounds)
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto sel(bool c, const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+  constexpr int L = La > Lb ? La : Lb;
+  constexpr int V = Va > Vb ? Va : Vb;
+  Fp<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto add(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return wrap2(add(a.v, b.v)); }
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto sub(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return wrap2(sub(a.v, b.v)); }
+template <int L, int V>
+BLS_HD auto neg(const Fp2<L, V>& a) { return wrap2(neg(a.v)); }
+template <int L, int V>
+BLS_HD auto dbl(const Fp2<L, V>& a) { return wrap2(dbl(a.v)); }
+template <int LT, int VT, int L, int V>
+BLS_HD auto fit(const Fp2<L, V>& a) { return wrap2(fit<LT, VT>(a.v)); }
+template <int L, int V>
+BLS_HD Fp2<L, V> select(bool c, const Fp2<L, V>& a, const Fp2<L, V>& b) { return Fp2<L, V>(select(c, a.v, b.v)); }
+
+// Operand bounds the fused product accepts: the a-side c1 coefficient is negated on the even lane (L+1, V+1).
+template <int La, int Va, int Lb, int Vb>
+struct Fp2MulFits {
+  static constexpr int ll = La * Lb + (La + 1) * Lb;
+  static constexpr int vv = Va * Vb + (Va + 1) * Vb;
+  static constexpr bool ok = ll <= MONT_LL_MAX && vv <= MONT_VV_MAX;
+};
+
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2R mul_raw(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+  static_assert(Fp2MulFits<La, Va, Lb, Vb>::ok, "fp2 mul: operand bounds too large (fit<> them first)");
+  const bool even = lane_part() == 0;
+  const Fp<La, Va> ao = swap(a.v);
+  const Fp<Lb, Vb> bo = swap(b.v);
+  const Fp<La, Va> a0 = select(even, a.v, ao);            // a0 on both lanes
+  const Fp<La, Va> a1 = select(even, ao, a.v);            // a1 on both lanes
+  const auto a1s = sel(even, neg(a1), a1);                // -a1 (even) / +a1 (odd)
+  return Fp2R(mul2(a0, b.v, a1s, bo));                    // even: a0 b0 - a1 b1 ; odd: a0 b1 + a1 b0
+}
+
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+  if constexpr (Fp2MulFits<La, Va, Lb, Vb>::ok) return mul_raw(a, b);
+  else if constexpr (Fp2MulFits<Lb, Vb, La, Va>::ok) return mul_raw(b, a);      // negate the other side instead
+  else if constexpr (Va * Vb + (Va + 1) * Vb > MONT_VV_MAX) {
+    if constexpr (Va >= Vb) return mul(fit<1, 2>(a), b); else return mul(a, fit<1, 2>(b));
+  } else {
+    if constexpr (La >= Lb) return mul(fit<1, Va>(a), b); else return mul(a, fit<1, Vb>(b));
+  }
+}
+
+// even: (a0 + a1)(a0 - a1) ; odd: (a0 + a0) a1      -- fq2_target_tree.rs:80-91
+template <int L, int V>
+BLS_HD Fp2R sqr(const Fp2<L, V>& a) {
+  if constexpr ((2 * L) * (2 * L + 1) <= MONT_LL_MAX && (2 * V) * (2 * V + 1) <= MONT_VV_MAX) {
+    const bool even = lane_part() == 0;
+    const Fp<L, V> o = swap(a.v);                          // even: a1 ; odd: a0
+    const auto x = add(select(even, a.v, o), o);           // even: a0 + a1 ; odd: a0 + a0
+    const auto y = sel(even, sub(a.v, o), a.v);            // even: a0 - a1 ; odd: a1
+    return Fp2R(mul(x, y));
+  } else if constexpr ((2 * V) * (2 * V + 1) > MONT_VV_MAX) {
+    return sqr(fit<1, 2>(a));
+  } else {
+    return sqr(fit<1, V>(a));
+  }
+}
+
+template <int L, int V, int Lk, int Vk>
+BLS_HD Fp2R mul_fp(const Fp2<L, V>& a, const Fp<Lk, Vk>& k) { return Fp2R(mul(a.v, k)); }
+
+template <int L, int V>
+BLS_HD auto conj(const Fp2<L, V>& a) { return wrap2(sel(lane_part() == 0, a.v, neg(a.v))); }
+
+// xi = 1 + u: (c0 - c1, c0 + c1)
+template <int L, int V>
+BLS_HD auto mul_xi(const Fp2<L, V>& a) {
+  const Fp<L, V> o = swap(a.v);
+  return wrap2(sel(lane_part() == 0, sub(a.v, o), add(a.v, o)));
+}
+
+// inverse via the norm; both lanes compute the (identical) Fp inverse.  Zero maps to zero.
+template <int L, int V>
+BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
+  const Fp2R a = fit<1, 2>(a_in);
+  const FpR o = swap(a.v);
+  const FpR n = mul2(a.v, a.v, o, o);
+  const FpR ni = fp_inv(n);
+  return Fp2R(mul(sel(lane_part() == 0, a.v, neg(a.v)), ni));
+}
+
+// pair-wide AND of a per-lane predicate
+BLS_HD bool pair_all(bool z) { return (dpp_swap(z ? 1u : 0u) & (z ? 1u : 0u)) != 0; }
+
+template <int L, int V>
+BLS_HD bool is_zero(const Fp2<L, V>& a) { return pair_all(is_zero(a.v)); }
+
+BLS_HD Fp2<1, 1> fp2_zero() { return Fp2<1, 1>(fp_zero()); }
+BLS_HD Fp2<1, 1> fp2_one() { return Fp2<1, 1>(select(lane_part() == 0, fp_one(), fp_zero())); }
+BLS_HD Fp2<1, 1> fp2_const(const uint32_t (&c0)[NL], const uint32_t (&c1)[NL]) {
+  return Fp2<1, 1>(select(lane_part() == 0, fp_const(c0), fp_const(c1)));
+}
+
+// each lane moves its own coefficient (48 contiguous bytes)
+BLS_HD Fp2R fp2_load(const uint64_t* w, int form) { return Fp2R(fp_load(w + 6 * lane_part(), form)); }
+template <int L, int V>
+BLS_HD void fp2_store(uint64_t* w, const Fp2<L, V>& a, int form) { fp_store(w + 6 * lane_part(), a.v, form); }
+
+}  // namespace bls

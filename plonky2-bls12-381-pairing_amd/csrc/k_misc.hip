@@ -8,20 +8,20 @@ using namespace bls;
 #ifndef BLS_MAX_BLOCK
 #define BLS_MAX_BLOCK 256
 #endif
-static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
 
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_final_exp(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   const Fp12R f = fp12_load(in + 72 * i, form);
   fp12_store(out + 72 * i, final_exponentiation(f), form);
-  if (flags) flags[i] = 0;
+  if (flags && lane_part() == 0) flags[i] = 0;
 }
 
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   if (op == BLS381_FP_TO_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_CANONICAL), IO_ARK_MONT); return; }
   if (op == BLS381_FP_FROM_MONT) { fp_store(out + 6 * i, fp_load(a + 6 * i, IO_ARK_MONT), IO_CANONICAL); return; }
@@ -40,7 +40,7 @@ k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, 
 
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_fp12_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   const Fp12R x = fp12_load(a + 72 * i, form);
   Fp12R r = x;
@@ -60,7 +60,7 @@ k_fp12_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_line_ref_opt(const uint64_t* __restrict__ q1, const uint64_t* __restrict__ q2, const uint64_t* __restrict__ p,
                uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   const G2Jac a = g2_jac_load(q1 + 36 * i, form), b = g2_jac_load(q2 + 36 * i, form);
   const G1Jac pt = g1_jac_load(p + 18 * i, form);
@@ -70,7 +70,7 @@ k_line_ref_opt(const uint64_t* __restrict__ q1, const uint64_t* __restrict__ q2,
 }
 
 __global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   fp12_store(out + 72 * i, Fp12R(fp12_one()), form);
 }

@@ -8,7 +8,7 @@ using namespace bls;
 #ifndef BLS_MAX_BLOCK
 #define BLS_MAX_BLOCK 256
 #endif
-static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
 
 #ifndef BLS_K
 #error "compile with -DBLS_K=1..4"
@@ -19,7 +19,7 @@ template <int K, bool FINAL_EXP>
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
                uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   G1Aff p[K]; G2Aff q[K]; bool skip[K];
   uint8_t fl = 0;
@@ -34,7 +34,7 @@ k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2,
   Fp12R f = miller_ate<K>(p, q, skip);
   if (FINAL_EXP) f = final_exponentiation(f);
   fp12_store(out + 72 * i, f, form);
-  if (flags) flags[i] = fl;
+  if (flags && lane_part() == 0) flags[i] = fl;
 }
 
 namespace bls_launch {

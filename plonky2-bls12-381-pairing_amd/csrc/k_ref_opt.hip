@@ -8,20 +8,20 @@ using namespace bls;
 #ifndef BLS_MAX_BLOCK
 #define BLS_MAX_BLOCK 256
 #endif
-static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
 
 template <bool GENERIC>
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_miller_ref_opt(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
                  uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   const G1Jac p = g1_jac_load(g1 + 18 * i, form);
   const G2Jac q = g2_jac_load(g2 + 36 * i, form);
   uint8_t fl = 0;
   const Fp12R f = miller_ref_opt<GENERIC>(p, q, fl);
   fp12_store(out + 72 * i, f, form);
-  if (flags) flags[i] = fl;
+  if (flags && lane_part() == 0) flags[i] = fl;
 }
 
 namespace bls_launch {

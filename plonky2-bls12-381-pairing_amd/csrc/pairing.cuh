@@ -97,6 +97,7 @@ BLS_HD_NOINLINE LineND line_chord(const G2Jac& q1, const G2Jac& q2, const G1Jac&
   return r;
 }
 
+BLS_HD Fp12R sqr_via_mul(const Fp12R& a) { return mul_call(a, a); }   // the reference squares with `f * f`
 BLS_HD Fp12R embed_fp2(const Fp2R& v) {        // Fq12::new(Fq6::new(v, 0, 0), Fq6::zero())  (:18-36)
   Fp12R r;
   r.c0 = Fp6R(v, Fp2R(fp2_zero()), Fp2R(fp2_zero()));
@@ -114,19 +115,19 @@ BLS_HD Fp12R miller_ref_opt(const G1Jac& p, const G2Jac& q, uint8_t& flags) {
     Fp12R f_num = fp12_one(), f_den = fp12_one();
     for (int i = 0; i < 64; ++i) {                                        // :89, bit i of BLS_X, LSB first
       const LineND t = line_tangent(r, p);                                // :90
-      f_num = mul(mul(f_num, f_num), embed_fp2(t.n));                     // :91
-      f_den = mul(mul(f_den, f_den), embed_fp2(t.d));                     // :92
+      f_num = mul_call(sqr_via_mul(f_num), embed_fp2(t.n));               // :91
+      f_den = mul_call(sqr_via_mul(f_den), embed_fp2(t.d));               // :92
       r = g2_jac_add(r, r);                                               // :93
       if ((BLS_X_PARAM >> i) & 1ull) {
         const LineND c = line_chord(r, q, p);                             // :95
-        f_num = mul(f_num, embed_fp2(c.n));                               // :96
-        f_den = mul(f_den, embed_fp2(c.d));                               // :97
+        f_num = mul_call(f_num, embed_fp2(c.n));                          // :96
+        f_den = mul_call(f_den, embed_fp2(c.d));                          // :97
         r = g2_jac_add(r, q);                                             // :98
       }
     }
     if (is_zero(f_den)) { flags |= FLAG_DEN_ZERO; }                       // :102 panics in the reference
-    Fp12R f = mul(f_num, inv(f_den));                                     // :102
-    return mul(f, f);                                                     // :116-121
+    Fp12R f = mul_call(f_num, inv(f_den));                                // :102
+    return mul_call(f, f);                                                // :116-121
   } else {
     Fp2R f_num = fp2_one(), f_den = fp2_one();
     for (int i = 0; i < 64; ++i) {
@@ -151,7 +152,7 @@ BLS_HD Fp12R miller_ref_opt(const G1Jac& p, const G2Jac& q, uint8_t& flags) {
 struct LineCoeffs { Fp2R a, b, c; };     // (tmp0, tmp3, tmp6) / (t10, t1, t9)
 
 // src/miller_loop_native.rs:27-55 (Alg. 26 of ePrint 2010/354)
-BLS_HD_NOINLINE LineCoeffs doubling_step(G2Jac& r) {
+BLS_HD LineCoeffs doubling_step(G2Jac& r) {
   const Fp2R tmp0 = sqr(r.x);
   const Fp2R tmp1 = sqr(r.y);
   const Fp2R tmp2 = sqr(tmp1);
@@ -172,7 +173,7 @@ BLS_HD_NOINLINE LineCoeffs doubling_step(G2Jac& r) {
 }
 
 // src/miller_loop_native.rs:58-87 (Alg. 27)
-BLS_HD_NOINLINE LineCoeffs addition_step(G2Jac& r, const G2Aff& q) {
+BLS_HD LineCoeffs addition_step(G2Jac& r, const G2Aff& q) {
   const Fp2R zsq = sqr(r.z);
   const Fp2R ysq = sqr(q.y);
   const Fp2R t0 = mul(zsq, q.x);
@@ -204,37 +205,41 @@ BLS_HD Fp12R ell(const Fp12R& f, const LineCoeffs& l, const G1Aff& p) {
   const Fp2R c1 = mul_fp(l.b, p.x);
   return mul_by_014(f, l.c, c1, c0);
 }
+BLS_HD_NOINLINE LineCoeffs doubling_step_call(G2Jac& r) { return doubling_step(r); }
+BLS_HD_NOINLINE LineCoeffs addition_step_call(G2Jac& r, const G2Aff& q) { return addition_step(r, q); }
+BLS_HD_NOINLINE Fp12R ell_call(const Fp12R& f, const LineCoeffs& l, const G1Aff& p) { return ell(f, l, p); }
 
 // Miller loop over N_PAIRS pairs with shared squarings: src/miller_loop_native.rs:89-116 driven the way
 // multi_miller_loop (:154-212) intends.  skip[j] marks a pair with a point at infinity (its lines are
 // skipped, like the commented `either_identity` select at :167-170).
+//
+// Schedule (:94-109): for the 62 bits of BLS_X >> 1 below its leading one, MSB first: doubling step, addition
+// step if the bit is set, then one squaring; after the loop one more doubling step; conjugate (x < 0).
+// The code below folds the trailing doubling step into the loop (iteration b = -1, no squaring) and walks the
+// (doubling, addition) steps of an iteration with a uniform `pass` loop, so the instruction stream holds ONE copy of
+// each step and of the sparse multiplication -- the loop body is the whole hot path and stays I-cache friendly.
 template <int N_PAIRS>
 BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
   G2Jac r[N_PAIRS];
 #pragma unroll
   for (int j = 0; j < N_PAIRS; ++j) { r[j].x = q[j].x; r[j].y = q[j].y; r[j].z = Fp2R(fp2_one()); }
   Fp12R f = fp12_one();
-  // bits of BLS_X >> 1 below its leading one, MSB first (:94-98): positions 61 .. 0
-  for (int b = 61; b >= 0; --b) {
-    const bool bit = ((BLS_X_PARAM >> 1) >> b) & 1ull;
+  for (int b = 61; b >= -1; --b) {
+    const bool last = b < 0;
+    const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      if constexpr (N_PAIRS == 1) {
+        const LineCoeffs l = (pass == 0) ? doubling_step(r[0]) : addition_step(r[0], q[0]);
+        if (!skip[0]) f = ell(f, l, p[0]);
+      } else {
 #pragma unroll
-    for (int j = 0; j < N_PAIRS; ++j) {
-      const LineCoeffs l = doubling_step(r[j]);
-      if (!skip[j]) f = ell(f, l, p[j]);
-    }
-    if (bit) {
-#pragma unroll
-      for (int j = 0; j < N_PAIRS; ++j) {
-        const LineCoeffs l = addition_step(r[j], q[j]);
-        if (!skip[j]) f = ell(f, l, p[j]);
+        for (int j = 0; j < N_PAIRS; ++j) {
+          const LineCoeffs l = (pass == 0) ? doubling_step_call(r[j]) : addition_step_call(r[j], q[j]);
+          if (!skip[j]) f = ell_call(f, l, p[j]);
+        }
       }
     }
-    f = sqr(f);                                                           // :106
-  }
-#pragma unroll
-  for (int j = 0; j < N_PAIRS; ++j) {                                     // :109
-    const LineCoeffs l = doubling_step(r[j]);
-    if (!skip[j]) f = ell(f, l, p[j]);
+    if (!last) f = (N_PAIRS == 1) ? sqr(f) : sqr_call(f);                 // :106
   }
   return fit<1, 2>(conj(f));                                              // :111-113 (x < 0)
 }

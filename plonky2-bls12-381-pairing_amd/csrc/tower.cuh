@@ -12,14 +12,23 @@
 // kept as loop state return "R" types (<1, 2>) by ending in fit<1, 2>().
 #pragma once
 #include "fp.cuh"
+#ifndef BLS_LANES
+#define BLS_LANES 1
+#endif
+#if BLS_LANES == 2
+#include "fp2_pair.cuh"
+#else
+#include "fp2_serial.cuh"
+#endif
 
-// Inlining granularity of the tower (tunable: code size vs call traffic).  Default: Fp2 products inline
-// into Fp6-level routines; Fp6/Fp12-level routines are real functions.
+// Inlining granularity of the tower (tunable: code size vs call traffic).  Serial backend: Fp2 products inline
+// into Fp6-level routines, Fp6/Fp12-level routines are real functions.  Lane-pair backend: everything inlines
+// into the (single-copy) hot loops; cold glue goes through the *_call wrappers below.
 #ifndef BLS_INLINE_FP6
-#define BLS_INLINE_FP6 0
+#define BLS_INLINE_FP6 (BLS_LANES == 2)
 #endif
 #ifndef BLS_INLINE_FP12
-#define BLS_INLINE_FP12 0
+#define BLS_INLINE_FP12 (BLS_LANES == 2)
 #endif
 #if BLS_INLINE_FP6
 #define BLS_FN_FP6 BLS_HD
@@ -33,114 +42,6 @@
 #endif
 
 namespace bls {
-
-// ================================================================================================ Fp2
-template <int L, int V>
-struct Fp2 {
-  Fp<L, V> c0, c1;
-  Fp2() = default;
-  BLS_HD Fp2(const Fp<L, V>& a, const Fp<L, V>& b) : c0(a), c1(b) {}
-  template <int L2, int V2>
-  BLS_HD Fp2(const Fp2<L2, V2>& o) : c0(o.c0), c1(o.c1) {}
-};
-using Fp2R = Fp2<1, 2>;
-
-// build an Fp2 from two Fp of (possibly) different bounds
-template <int L0, int V0, int L1, int V1>
-BLS_HD auto make_fp2(const Fp<L0, V0>& a, const Fp<L1, V1>& b) {
-  constexpr int L = L0 > L1 ? L0 : L1;
-  constexpr int V = V0 > V1 ? V0 : V1;
-  return Fp2<L, V>(Fp<L, V>(a), Fp<L, V>(b));
-}
-template <int La, int Va, int Lb, int Vb>
-BLS_HD auto add(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return make_fp2(add(a.c0, b.c0), add(a.c1, b.c1)); }
-template <int La, int Va, int Lb, int Vb>
-BLS_HD auto sub(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return make_fp2(sub(a.c0, b.c0), sub(a.c1, b.c1)); }
-template <int L, int V>
-BLS_HD auto neg(const Fp2<L, V>& a) { return make_fp2(neg(a.c0), neg(a.c1)); }
-template <int L, int V>
-BLS_HD auto dbl(const Fp2<L, V>& a) { return make_fp2(dbl(a.c0), dbl(a.c1)); }
-template <int LT, int VT, int L, int V>
-BLS_HD auto fit(const Fp2<L, V>& a) { return make_fp2(fit<LT, VT>(a.c0), fit<LT, VT>(a.c1)); }
-template <int L, int V>
-BLS_HD Fp2<L, V> select(bool c, const Fp2<L, V>& a, const Fp2<L, V>& b) {
-  return Fp2<L, V>(select(c, a.c0, b.c0), select(c, a.c1, b.c1));
-}
-
-// Largest operand bounds the fused schoolbook product accepts: with the c1 operand of the lower-L side
-// negated (L + 1, V + 1):  La*Lb + (Lmin + 1)*Lmax <= 17  and  Va*Vb + (Vneg + 1)*Vother <= 2500.
-template <int La, int Va, int Lb, int Vb>
-struct Fp2MulFits {
-  static constexpr bool neg_a = (La <= Lb);
-  static constexpr int ll = La * Lb + (neg_a ? (La + 1) * Lb : (Lb + 1) * La);
-  static constexpr int vv = Va * Vb + (neg_a ? (Va + 1) * Vb : (Vb + 1) * Va);
-  static constexpr bool ok = ll <= MONT_LL_MAX && vv <= MONT_VV_MAX;
-};
-
-// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u   -- fq2_target_tree.rs:97-115
-template <int La, int Va, int Lb, int Vb>
-BLS_HD Fp2R mul_raw(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
-  using F = Fp2MulFits<La, Va, Lb, Vb>;
-  static_assert(F::ok, "fp2 mul: operand bounds too large (fit<> them first)");
-  if constexpr (F::neg_a)
-    return Fp2R(mul2(a.c0, b.c0, neg(a.c1), b.c1), mul2(a.c0, b.c1, a.c1, b.c0));
-  else
-    return Fp2R(mul2(a.c0, b.c0, a.c1, neg(b.c1)), mul2(a.c0, b.c1, a.c1, b.c0));
-}
-
-// Multiplication with automatic operand conditioning: normalise / weakly reduce whichever operand makes
-// the fused product overflow its static bounds.
-template <int La, int Va, int Lb, int Vb>
-BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
-  if constexpr (Fp2MulFits<La, Va, Lb, Vb>::ok) return mul_raw(a, b);
-  else if constexpr (Va * Vb + (Va + 1) * Vb > MONT_VV_MAX) {
-    if constexpr (Va >= Vb) return mul(fit<1, 2>(a), b); else return mul(a, fit<1, 2>(b));
-  } else {
-    if constexpr (La >= Lb) return mul(fit<1, Va>(a), b); else return mul(a, fit<1, Vb>(b));
-  }
-}
-
-// complex squaring (a0+a1)(a0-a1), 2 a0 a1   -- fq2_target_tree.rs:80-91
-template <int L, int V>
-BLS_HD Fp2R sqr(const Fp2<L, V>& a) {
-  if constexpr ((2 * L) * (2 * L + 1) <= MONT_LL_MAX && (2 * V) * (2 * V + 1) <= MONT_VV_MAX) {
-    return Fp2R(mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1));
-  } else if constexpr ((2 * V) * (2 * V + 1) > MONT_VV_MAX) {
-    return sqr(fit<1, 2>(a));
-  } else {
-    return sqr(fit<1, V>(a));
-  }
-}
-
-// Fp2 x Fp (line evaluation scaling, src/miller_loop_native.rs:143-147 commented `ell`)
-template <int L, int V, int Lk, int Vk>
-BLS_HD Fp2R mul_fp(const Fp2<L, V>& a, const Fp<Lk, Vk>& k) { return Fp2R(mul(a.c0, k), mul(a.c1, k)); }
-
-template <int L, int V>
-BLS_HD auto conj(const Fp2<L, V>& a) { return make_fp2(a.c0, neg(a.c1)); }   // fq2_target_tree.rs:117-122
-
-// multiply by xi = 1 + u: (c0 - c1, c0 + c1)   -- fq2_target_tree.rs:137-142
-template <int L, int V>
-BLS_HD auto mul_xi(const Fp2<L, V>& a) { return make_fp2(sub(a.c0, a.c1), add(a.c0, a.c1)); }
-
-// inverse via the norm (fq2_target_tree.rs:66-78); zero maps to zero.
-template <int L, int V>
-BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
-  const Fp2R a = fit<1, 2>(a_in);
-  const FpR n = mul2(a.c0, a.c0, a.c1, a.c1);
-  const FpR ni = fp_inv(n);
-  return Fp2R(mul(a.c0, ni), mul(neg(a.c1), ni));
-}
-
-template <int L, int V>
-BLS_HD bool is_zero(const Fp2<L, V>& a) { return is_zero(a.c0) & is_zero(a.c1); }
-
-BLS_HD Fp2<1, 1> fp2_zero() { return Fp2<1, 1>(fp_zero(), fp_zero()); }
-BLS_HD Fp2<1, 1> fp2_one() { return Fp2<1, 1>(fp_one(), fp_zero()); }
-
-BLS_HD Fp2R fp2_load(const uint64_t* w, int form) { return Fp2R(fp_load(w, form), fp_load(w + 6, form)); }
-template <int L, int V>
-BLS_HD void fp2_store(uint64_t* w, const Fp2<L, V>& a, int form) { fp_store(w, a.c0, form); fp_store(w + 6, a.c1, form); }
 
 // ================================================================================================ Fp6
 template <int L, int V>
@@ -243,8 +144,8 @@ BLS_HD Fp6<1, 1> fp6_one() { return Fp6<1, 1>(fp2_one(), fp2_zero(), fp2_zero())
 // Frobenius   -- fq6_target_tree.rs:129-169, constants canonical (fp_consts.h)
 template <int L, int V>
 BLS_HD Fp6R frobenius(const Fp6<L, V>& a) {
-  const Fp2<1, 1> k1(fp_const(BLS_FROB6_C1_C0), fp_const(BLS_FROB6_C1_C1));
-  const Fp2<1, 1> k2(fp_const(BLS_FROB6_C2_C0), fp_const(BLS_FROB6_C2_C1));
+  const Fp2<1, 1> k1 = fp2_const(BLS_FROB6_C1_C0, BLS_FROB6_C1_C1);
+  const Fp2<1, 1> k2 = fp2_const(BLS_FROB6_C2_C0, BLS_FROB6_C2_C1);
   return Fp6R(fit<1, 2>(conj(a.c0)), mul(conj(a.c1), k1), mul(conj(a.c2), k2));
 }
 
@@ -311,7 +212,7 @@ BLS_HD_NOINLINE Fp12R inv(const Fp12<L, V>& a_in) {
 // Frobenius   -- fq12_target_tree.rs:92-128
 template <int L, int V>
 BLS_FN_FP12 Fp12R frobenius(const Fp12<L, V>& a) {
-  const Fp2<1, 1> k(fp_const(BLS_FROB12_C1_C0), fp_const(BLS_FROB12_C1_C1));
+  const Fp2<1, 1> k = fp2_const(BLS_FROB12_C1_C0, BLS_FROB12_C1_C1);
   const Fp6R c0 = frobenius(a.c0);
   const Fp6R c1 = frobenius(a.c1);
   return Fp12R(c0, Fp6R(mul(c1.c0, k), mul(c1.c1, k), mul(c1.c2, k)));
@@ -329,6 +230,13 @@ BLS_FN_FP12 Fp12R mul_by_014(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const F
   const auto r0 = add(mul_v(bb), aa);
   return Fp12R(fit<1, 2>(r0), fit<1, 2>(r1));
 }
+
+// Out-of-line entry points for cold call sites (final-exponentiation glue, reference-mode accumulators): one
+// shared copy of each routine however BLS_FN_FP12 is set.
+BLS_HD_NOINLINE Fp12R mul_call(const Fp12R& a, const Fp12R& b) { return mul(a, b); }
+BLS_HD_NOINLINE Fp12R sqr_call(const Fp12R& a) { return sqr(a); }
+BLS_HD_NOINLINE Fp12R frobenius_call(const Fp12R& a) { return frobenius(a); }
+BLS_HD_NOINLINE Fp12R cyclotomic_square_call(const Fp12R& a);
 
 // ---- cyclotomic subgroup (final exponentiation)   -- src/fields_as_trees/miller_loop.rs:29-126
 template <class A, class B> struct Pair2 { A a; B b; };
@@ -363,6 +271,8 @@ BLS_FN_FP12 Fp12R cyclotomic_square(const Fp12<L, V>& f) {
                Fp6R(fit<1, 2>(n2), fit<1, 2>(n1), fit<1, 2>(n5)));
 }
 
+BLS_HD_NOINLINE Fp12R cyclotomic_square_call(const Fp12R& a) { return cyclotomic_square(a); }
+
 // conj(f^|x|), MSB-first square-and-multiply over BLS_X   -- miller_loop.rs:106-126, with the product the
 // reference drops at :121 kept.
 BLS_HD_NOINLINE Fp12R cyclotomic_exp(const Fp12R& f) {
@@ -378,30 +288,30 @@ BLS_HD_NOINLINE Fp12R cyclotomic_exp(const Fp12R& f) {
 BLS_HD_NOINLINE Fp12R final_exponentiation(const Fp12R& f) {
   const Fp12R t0f = fit<1, 2>(conj(f));                   // frobenius^6 == conjugation (:168-174)
   Fp12R t1 = inv(f);                                      // :175
-  Fp12R t2 = mul(t0f, t1);                                // :133
+  Fp12R t2 = mul_call(t0f, t1);                                // :133
   t1 = t2;
-  t2 = mul(frobenius(frobenius(t2)), t1);                 // :135-136
-  t1 = fit<1, 2>(conj(cyclotomic_square(t2)));            // :137
+  t2 = mul_call(frobenius_call(frobenius_call(t2)), t1);                 // :135-136
+  t1 = fit<1, 2>(conj(cyclotomic_square_call(t2)));       // :137
   Fp12R t3 = cyclotomic_exp(t2);
-  Fp12R t4 = cyclotomic_square(t3);
-  Fp12R t5 = mul(t1, t3);
+  Fp12R t4 = cyclotomic_square_call(t3);
+  Fp12R t5 = mul_call(t1, t3);
   t1 = cyclotomic_exp(t5);
   Fp12R t0 = cyclotomic_exp(t1);
   Fp12R t6 = cyclotomic_exp(t0);
-  t6 = mul(t6, t4);
+  t6 = mul_call(t6, t4);
   t4 = cyclotomic_exp(t6);
   t5 = fit<1, 2>(conj(t5));
-  t4 = mul(t4, mul(t5, t2));
+  t4 = mul_call(t4, mul_call(t5, t2));
   t5 = fit<1, 2>(conj(t2));
-  t1 = mul(t1, t2);
-  t1 = frobenius(frobenius(frobenius(t1)));
-  t6 = mul(t6, t5);
-  t6 = frobenius(t6);
-  t3 = mul(t3, t0);
-  t3 = frobenius(frobenius(t3));
-  t3 = mul(t3, t1);
-  t3 = mul(t3, t6);
-  return mul(t3, t4);
+  t1 = mul_call(t1, t2);
+  t1 = frobenius_call(frobenius_call(frobenius_call(t1)));
+  t6 = mul_call(t6, t5);
+  t6 = frobenius_call(t6);
+  t3 = mul_call(t3, t0);
+  t3 = frobenius_call(frobenius_call(t3));
+  t3 = mul_call(t3, t1);
+  t3 = mul_call(t3, t6);
+  return mul_call(t3, t4);
 }
 
 template <int L, int V>
