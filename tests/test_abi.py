@@ -52,3 +52,15 @@ def test_product_sources_never_touch_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyref" not in txt and "bls381_oracle" not in txt and "hostsim" not in txt.replace("tests/hostsim", ""), os.path.join(dirpath, f)
+
+
+def test_cpp_host_mirror_compiles():
+    """plonky2-bls12-381-pairing_amd/host/bls381_pairing.hpp (C++ mirror of the reference interface) is well-formed
+    and links against the library."""
+    import subprocess, tempfile
+    src = os.path.join(ROOT, "tests", "host_mirror_check.cpp")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "host_mirror_check")
+        subprocess.check_call(["g++", "-std=c++17", src, "-o", exe, "-L", os.path.dirname(B.LIB_PATH), "-lbls381_hip",
+                               "-Wl,-rpath," + os.path.dirname(B.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+        assert subprocess.call([exe]) == 0      # without a GPU the Backend constructor throws PairingError -> exit 0
