@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,16 +55,23 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     import torch.distributed as dist
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     import bls381_amd as B
     from blsutil import synthetic_batch
 
     n = 1 << args.batch_log2
-    eng = B.Engine(local_rank)
+    eng = B.Engine(dev_index)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.block:
         eng.set_option(B.OPT_BLOCK_SIZE, args.block)
@@ -101,7 +110,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -53,6 +53,10 @@ constexpr int MONT_VV_MAX = 2500;
 // Host-only instrumentation (tests/hostsim): verifies at run time that the compile-time bounds hold.
 void bound_check_fail(const char* what);
 void bound_check(const uint32_t* l, int L, int V);
+extern long g_op_count[8];   // 0 mul, 1 mul2, 2 sqr, 3 weak_reduce, 4 norm, 5 add/sub/neg/dbl
+#define BLS_COUNT(k) (++::bls::g_op_count[k])
+#else
+#define BLS_COUNT(k) ((void)0)
 #endif
 
 template <int L, int V>
@@ -172,6 +176,7 @@ template <int La, int Va, int Lb, int Vb>
 BLS_HD FpR mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
   static_assert(La * Lb <= MONT_LL_MAX, "mul: limb bounds overflow the 64-bit column accumulator");
   static_assert(Va * Vb <= MONT_VV_MAX, "mul: value bounds break the < 2p result guarantee");
+  BLS_COUNT(0);
   FpR r = fp_of(mont1_raw(raw_of(a), raw_of(b)));
   r.chk();
   return r;
@@ -183,6 +188,7 @@ BLS_HD FpR sqr(const Fp<La, Va>& a) {
   static_assert(2 * La * La <= MONT_LL_MAX * 2, "sqr: limb bounds overflow");   // same column total as a*a
   static_assert(La * La <= MONT_LL_MAX, "sqr: limb bounds overflow");
   static_assert(Va * Va <= MONT_VV_MAX, "sqr: value bounds");
+  BLS_COUNT(2);
   FpR r = fp_of(montsqr_raw(raw_of(a)));
   r.chk();
   return r;
@@ -193,6 +199,7 @@ template <int La, int Va, int Lb, int Vb, int Lc, int Vc, int Ld, int Vd>
 BLS_HD FpR mul2(const Fp<La, Va>& a, const Fp<Lb, Vb>& b, const Fp<Lc, Vc>& c, const Fp<Ld, Vd>& d) {
   static_assert(La * Lb + Lc * Ld <= MONT_LL_MAX, "mul2: limb bounds overflow the 64-bit column accumulator");
   static_assert(Va * Vb + Vc * Vd <= MONT_VV_MAX, "mul2: value bounds break the < 2p result guarantee");
+  BLS_COUNT(1);
   FpR r = fp_of(mont2_raw(raw_of(a), raw_of(b), raw_of(c), raw_of(d)));
   r.chk();
   return r;
@@ -268,6 +275,7 @@ BLS_HD auto neg(const Fp<Lb, Vb>& b) {
 // One parallel carry pass: limbs come back to 28 bits (+ at most L units), value unchanged.
 template <int L, int V>
 BLS_HD Fp<1, V> norm(const Fp<L, V>& a) {
+  BLS_COUNT(4);
   Fp<1, V> r;
   r.l[0] = a.l[0] & LMASK;
 #pragma unroll
@@ -287,16 +295,22 @@ constexpr uint64_t WR_M = ((uint64_t)1 << 40) / (uint64_t)(P_HI + 1);
 template <int L, int V>
 BLS_HD FpR weak_reduce(const Fp<L, V>& a) {
   static_assert(V <= 64, "weak_reduce: value bound too large for the quotient estimate");
-  const Fp<1, V> n = norm(a);
-  const uint32_t q = (uint32_t)(((uint64_t)n.l[NL - 1] * WR_M) >> 40);
+  static_assert(L <= L_CAP, "weak_reduce: limb bound");
+  BLS_COUNT(3);
+  // top 28-bit digit of the value, short by at most one unit (carries still pending below limb 12)
+  const uint32_t top = a.l[NL - 1] + (a.l[NL - 2] >> LW);
+  const uint32_t q = (uint32_t)(((uint64_t)top * WR_M) >> 40);
+  // x + q * (2^392 - p) with an exact carry chain; the 2^392 multiples fall off the top limb.
+  // Four instructions per limb: one MAD (carry as the 64-bit addend), one 64-bit add of the limb, mask, shift.
   FpR r;
-  uint64_t acc = 0;
+  uint64_t carry = 0;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const uint32_t ci = (i < NL - 1) ? (LMASK - BLS_P28[i] + (i == 0 ? 1u : 0u)) : (LMASK - BLS_P28[i]);
-    acc += (uint64_t)q * ci + n.l[i];
+    uint64_t acc = (uint64_t)q * ci + carry;
+    acc += a.l[i];
     r.l[i] = (uint32_t)acc & LMASK;
-    acc >>= LW;
+    carry = acc >> LW;
   }
   r.chk();
   return r;

@@ -13,6 +13,7 @@
 namespace bls {
 
 static long g_checks = 0;
+long g_op_count[8] = {0};
 static int g_max_l_seen = 0;
 
 void bound_check_fail(const char* what) {
@@ -56,6 +57,7 @@ using namespace bls;
 extern "C" {
 
 long hostsim_bound_checks() { return bls::g_checks; }
+void hostsim_op_counts(long* out, int reset) { for (int i = 0; i < 8; ++i) { out[i] = bls::g_op_count[i]; if (reset) bls::g_op_count[i] = 0; } }
 
 // op codes shared with include/bls381_hip.h
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_INV = 4, OP_NEG = 5, OP_TO_MONT = 6, OP_FROM_MONT = 7 };

@@ -200,3 +200,32 @@ def test_mode_a_64k_batch_properties(engine, coracle):
     o = out.reshape(n // pool, pool * 72)
     exp, _ = coracle.miller_ref_opt(g1[: pool * 18], g2[: pool * 36], threads=16)
     assert np.array_equal(o[0], exp) and (o == o[0]).all() and not fl.any()
+
+
+def test_device_pointer_api_on_caller_stream(engine, coracle):
+    """The `_dev` entry points (what bench.py times): device buffers owned by the caller, launches enqueued on an
+    adopted stream, no implicit synchronisation."""
+    import torch
+    n = 512
+    g1, g2 = synthetic_batch(n, seed=77, jacobian=False, pool=32)
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev); d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    out = torch.zeros(n * 72, dtype=torch.int64, device=dev); fl = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+    engine.set_stream(stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            engine.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), 1, out.data_ptr(), fl.data_ptr(), n)
+        stream.synchronize()
+        assert engine.last_kernel_ms() > 0
+    finally:
+        engine.set_stream(None)
+    exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=8)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), exp) and np.array_equal(fl.cpu().numpy(), efl)
+    # Miller-only and final-exponentiation device entry points compose to the same result
+    mid = torch.zeros(n * 72, dtype=torch.int64, device=dev)
+    engine.multi_miller_loop_dev(d1.data_ptr(), d2.data_ptr(), 1, mid.data_ptr(), 0, n)
+    out2 = torch.zeros(n * 72, dtype=torch.int64, device=dev)
+    engine.final_exponentiation_dev(mid.data_ptr(), out2.data_ptr(), 0, n)
+    engine.sync()
+    assert torch.equal(out, out2)

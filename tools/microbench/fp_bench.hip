@@ -12,9 +12,42 @@ using namespace bls;
 
 constexpr int ITERS = 256;
 
-enum { OP_MUL, OP_MUL2, OP_SQR, OP_ADDSUB, OP_FP2MUL, N_OPS };
-static const char* names[] = {"mont mul (a*b)", "mont mul2 (a*b+c*d)", "mont sqr", "add+sub pair", "fp2 mul (2x mul2 + neg)"};
-static const double mads[] = {392, 588, 301, 0, 1176};
+enum { OP_MUL, OP_MUL2, OP_SQR, OP_ADDSUB, OP_FP2MUL, OP_MUL2_PINNED, N_OPS };
+
+// mul2 with every MAD pinned into ONE accumulator chain per column by inline asm (no compiler re-association,
+// hence no 64-bit merge adds); tests whether a strictly sequential chain is latency-bound at low occupancy.
+__device__ __forceinline__ void mad_pin(uint64_t& acc, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ FpR mul2_pinned(const FpR& a, const FpR& b, const FpR& c, const FpR& d) {
+  uint32_t m[NL]; FpR out; uint64_t acc = 0;
+  uint32_t P[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) P[i] = BLS_P28[i];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) { mad_pin(acc, a.l[i], b.l[k - i]); mad_pin(acc, c.l[i], d.l[k - i]); }
+#pragma unroll
+    for (int i = 0; i < k; ++i) mad_pin(acc, m[i], P[k - i]);
+    m[k] = ((uint32_t)acc * BLS_PINV28) & LMASK;
+    mad_pin(acc, m[k], P[0]);
+    acc >>= LW;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) { mad_pin(acc, a.l[i], b.l[k - i]); mad_pin(acc, c.l[i], d.l[k - i]); }
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) mad_pin(acc, m[i], P[k - i]);
+    out.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LW;
+  }
+  out.l[NL - 1] = (uint32_t)acc;
+  return out;
+}
+static const char* names[] = {"mont mul (a*b)", "mont mul2 (a*b+c*d)", "mont sqr", "add+sub pair", "fp2 mul (2x mul2 + neg)", "mul2 pinned chain"};
+static const double mads[] = {392, 588, 301, 0, 1176, 588};
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_fp(const uint64_t* in, uint64_t* out, int iters) {
@@ -24,6 +57,7 @@ __global__ void __launch_bounds__(256) k_fp(const uint64_t* in, uint64_t* out, i
   for (int i = 0; i < iters; ++i) {
     if (OP == OP_MUL) { x = mul(x, y); y = mul(y, x); }
     else if (OP == OP_MUL2) { x = mul2(x, y, z, w); z = mul2(z, x, y, w); }
+    else if (OP == OP_MUL2_PINNED) { x = mul2_pinned(x, y, z, w); z = mul2_pinned(z, x, y, w); }
     else if (OP == OP_SQR) { x = sqr(x); y = sqr(y); }
     else if (OP == OP_ADDSUB) {
 #pragma unroll
@@ -77,5 +111,6 @@ int main() {
   if (run<OP_SQR>(d_in, d_out, n_cu)) return 1;
   if (run<OP_FP2MUL>(d_in, d_out, n_cu)) return 1;
   if (run<OP_ADDSUB>(d_in, d_out, n_cu)) return 1;
+  if (run<OP_MUL2_PINNED>(d_in, d_out, n_cu)) return 1;
   return 0;
 }
