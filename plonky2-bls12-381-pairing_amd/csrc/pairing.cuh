@@ -12,6 +12,12 @@
 #pragma once
 #include "tower.cuh"
 
+// up to this many pairs the multi-pairing loop inlines one copy of the step routines per pair (state stays in
+// registers); beyond it the steps are calls
+#ifndef BLS_INLINE_PAIRS_MAX
+#define BLS_INLINE_PAIRS_MAX (BLS_LANES == 2 ? 3 : 1)
+#endif
+
 namespace bls {
 
 enum : uint8_t { FLAG_DEN_ZERO = 1, FLAG_INFINITY = 2 };
@@ -228,9 +234,12 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
     const bool last = b < 0;
     const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {
-      if constexpr (N_PAIRS == 1) {
-        const LineCoeffs l = (pass == 0) ? doubling_step(r[0]) : addition_step(r[0], q[0]);
-        if (!skip[0]) f = ell(f, l, p[0]);
+      if constexpr (N_PAIRS <= BLS_INLINE_PAIRS_MAX) {
+#pragma unroll
+        for (int j = 0; j < N_PAIRS; ++j) {
+          const LineCoeffs l = (pass == 0) ? doubling_step(r[j]) : addition_step(r[j], q[j]);
+          if (!skip[j]) f = ell(f, l, p[j]);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < N_PAIRS; ++j) {
@@ -239,7 +248,7 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
         }
       }
     }
-    if (!last) f = (N_PAIRS == 1) ? sqr(f) : sqr_call(f);                 // :106
+    if (!last) f = (N_PAIRS <= BLS_INLINE_PAIRS_MAX) ? sqr(f) : sqr_call(f);   // :106
   }
   return fit<1, 2>(conj(f));                                              // :111-113 (x < 0)
 }
