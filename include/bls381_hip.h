@@ -113,6 +113,27 @@ int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_
 int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
+/* Witness-generator backend: batch forms of the `SimpleGenerator::run_once` hooks through which
+ * plonky2 invokes native arithmetic while filling a witness.  Elements are CANONICAL integers as 12 x u32
+ * little-endian digits per Fp (the BigUint limb format of FqTarget, src/fields/fq_target.rs:289-313; identical in
+ * memory to 6 x u64), Fq12 / Fq6 in the flat MyFq12 / MyFq6 coefficient orders (src/fields/helpers.rs:39-41,
+ * src/fields/my_fq6.rs:25).  Independent of BLS381_OPT_IO_FORM.  Extra flag bits: */
+enum {
+  BLS381_FLAG_NO_INVERSE = 4,          /* zero input where the generator does `inverse().unwrap()` */
+  BLS381_FLAG_NOT_SQUARE = 8,          /* `sqrt().unwrap()` would panic */
+  BLS381_FLAG_SIGN_UNSATISFIABLE = 16  /* root is 0 but sgn = 1 requested: the generator's assert_eq! fails */
+};
+/* Fq12InverseGenerator::run_once, src/fields/fq12_target.rs:351-374.  x, inv: n x 12 x 12 u32 */
+int bls381_witness_fq12_inverse_batch(bls381_ctx* ctx, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n);
+/* Fq6InverseGenerator::run_once, src/fields/fq6_target.rs:395-418.  x, inv: n x 6 x 12 u32 */
+int bls381_witness_fq6_inverse_batch(bls381_ctx* ctx, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n);
+/* Fq2InverseGenerator::run_once, src/fields/fq2_target.rs:331-352 (zero maps to zero).  x, inv: n x 2 x 12 u32 */
+int bls381_witness_fq2_inverse_batch(bls381_ctx* ctx, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n);
+/* FqSqrtGenerator::run_once, src/fields/fq_target.rs:330-343: the root whose sgn0 (parity) equals sgn[i] & 1 */
+int bls381_witness_fq_sqrt_batch(bls381_ctx* ctx, const uint32_t* x, const uint8_t* sgn, uint32_t* sqrt, uint8_t* flags, size_t n);
+/* Fq2SqrtGenerator::run_once, src/fields/fq2_target.rs:385-410 (sgn0_fq2, src/fields/helpers.rs:169-174) */
+int bls381_witness_fq2_sqrt_batch(bls381_ctx* ctx, const uint32_t* x, const uint8_t* sgn, uint32_t* sqrt, uint8_t* flags, size_t n);
+
 /* Test surface for the private `optimized_line_function` (src/miller_loop_native_optimized.rs:8-78): all three
  * branches, including the vertical one (:62-77) the loop never reaches on subgroup inputs.
  * q1_jac, q2_jac: n x 3 x 2 x 6, p_jac: n x 3 x 6, out_nd: n x (n, d) = n x 2 x 2 x 6. */

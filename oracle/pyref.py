@@ -842,6 +842,113 @@ def multi_pairing(terms):
     return final_exponentiation(multi_miller_loop(terms))
 
 
+# ================================================================ witness-generator hooks
+# The native arithmetic plonky2 runs while filling a witness.
+
+WFLAG_NO_INVERSE, WFLAG_NOT_SQUARE, WFLAG_SIGN_UNSATISFIABLE = 4, 8, 16
+
+
+def sgn0_fq(x):
+    """src/fields/helpers.rs:159-167: lowest bit of the canonical integer (false for zero)."""
+    return (x % P) & 1 == 1
+
+
+def sgn0_fq2(x):
+    """src/fields/helpers.rs:169-174."""
+    return sgn0_fq(x[0]) or (x[0] % P == 0 and sgn0_fq(x[1]))
+
+
+def fp_sqrt_any(x):
+    """Some square root of x or None (p = 3 mod 4: x^((p+1)/4))."""
+    s = pow(x, (P + 1) // 4, P)
+    return s if (s * s - x) % P == 0 else None
+
+
+def fp2_sqrt_any(x):
+    """Some square root of x in Fp2 or None, by brute algebra independent of the device algorithm:
+    solve (c0 + c1 u)^2 = a + b u  <=>  c0^2 - c1^2 = a, 2 c0 c1 = b."""
+    a, b = x[0] % P, x[1] % P
+    if b == 0:
+        s = fp_sqrt_any(a)
+        if s is not None:
+            return (s, 0)
+        t = fp_sqrt_any((-a) % P)
+        return None if t is None else (0, t)
+    n = (a * a + b * b) % P
+    sn = fp_sqrt_any(n)
+    if sn is None:
+        return None
+    inv2 = pow(2, P - 2, P)
+    for d in (((a + sn) * inv2) % P, ((a - sn) * inv2) % P):
+        c0 = fp_sqrt_any(d)
+        if c0 is not None and c0 != 0:
+            c1 = (b * pow(2 * c0, P - 2, P)) % P
+            if ((c0 * c0 - c1 * c1 - a) % P, (2 * c0 * c1 - b) % P) == (0, 0):
+                return (c0, c1)
+    return None
+
+
+def witness_fq_sqrt(x, sgn):
+    """FqSqrtGenerator::run_once, src/fields/fq_target.rs:330-343 -> (root, flags)."""
+    s = fp_sqrt_any(x % P)
+    if s is None:
+        return 0, WFLAG_NOT_SQUARE                       # sqrt().unwrap() panics
+    if sgn0_fq(s) != bool(sgn & 1):
+        s = (-s) % P
+    if sgn0_fq(s) != bool(sgn & 1):
+        return s, WFLAG_SIGN_UNSATISFIABLE               # assert_eq! at :340 fails (only for the root 0)
+    return s, 0
+
+
+def witness_fq2_sqrt(x, sgn):
+    """Fq2SqrtGenerator::run_once, src/fields/fq2_target.rs:385-410 -> (root, flags)."""
+    s = fp2_sqrt_any(x)
+    if s is None:
+        return (0, 0), WFLAG_NOT_SQUARE
+    if sgn0_fq2(s) != bool(sgn & 1):
+        s = ((-s[0]) % P, (-s[1]) % P)
+    if sgn0_fq2(s) != bool(sgn & 1):
+        return s, WFLAG_SIGN_UNSATISFIABLE
+    return s, 0
+
+
+def witness_fq2_inverse(x):
+    """Fq2InverseGenerator::run_once, src/fields/fq2_target.rs:331-352: None -> zero."""
+    r = fp2_inv((x[0] % P, x[1] % P))
+    return (0, 0) if r is None else r
+
+
+def fp6_to_myfq6(a):
+    """src/fields/my_fq6.rs:12-27: coeffs = [c00, c10, c20, c01, c11, c21]."""
+    return [a[0][0], a[1][0], a[2][0], a[0][1], a[1][1], a[2][1]]
+
+
+def myfq6_to_fp6(c):
+    return ((c[0], c[3]), (c[1], c[4]), (c[2], c[5]))
+
+
+def myfq12_to_fp12(c):
+    """src/fields/helpers.rs:45-76."""
+    q = lambda k: (c[k], c[k + 6])
+    return ((q(0), q(2), q(4)), (q(1), q(3), q(5)))
+
+
+def witness_fq6_inverse(coeffs):
+    """Fq6InverseGenerator::run_once, src/fields/fq6_target.rs:395-418 on MyFq6 coefficients -> (coeffs, flags)."""
+    r = fp6_inv(myfq6_to_fp6([c % P for c in coeffs]))
+    if r is None:
+        return [0] * 6, WFLAG_NO_INVERSE                 # inverse().unwrap() panics
+    return fp6_to_myfq6(r), 0
+
+
+def witness_fq12_inverse(coeffs):
+    """Fq12InverseGenerator::run_once, src/fields/fq12_target.rs:351-374 on MyFq12 coefficients."""
+    r = fp12_inv(myfq12_to_fp12([c % P for c in coeffs]))
+    if r is None:
+        return [0] * 12, WFLAG_NO_INVERSE
+    return fp12_to_myfq12(r), 0
+
+
 # ----------------------------------------------------------------- synthetic batches
 SEED = 0x424C533132333831      # ASCII "BLS12381" (SURVEY 8d)
 

@@ -286,6 +286,45 @@ int bls381_debug_line_ref_opt_batch(bls381_ctx* c, const uint64_t* q1, const uin
                       });
 }
 
+// ---- witness-generator backend (canonical 12 x u32 digits == 6 x u64 per Fp)
+static int witness_inverse(bls381_ctx* c, int op, size_t fp_per_elem, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n) {
+  if (!c || (n && (!x || !inv))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  const size_t bytes = n * fp_per_elem * 48;
+  return with_staging(c, x, bytes, nullptr, 0, inv, bytes, flags, n,
+                      [&](const uint64_t* dx, const uint64_t*, uint64_t* o, uint8_t* f) -> int {
+                        bls_launch::witness_inverse(op, dx, o, f, n, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+int bls381_witness_fq12_inverse_batch(bls381_ctx* c, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n) {
+  return witness_inverse(c, 0, 12, x, inv, flags, n);
+}
+int bls381_witness_fq6_inverse_batch(bls381_ctx* c, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n) {
+  return witness_inverse(c, 1, 6, x, inv, flags, n);
+}
+int bls381_witness_fq2_inverse_batch(bls381_ctx* c, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n) {
+  return witness_inverse(c, 2, 2, x, inv, flags, n);
+}
+static int witness_sqrt(bls381_ctx* c, int op, size_t fp_per_elem, const uint32_t* x, const uint8_t* sgn, uint32_t* out, uint8_t* flags, size_t n) {
+  if (!c || (n && (!x || !sgn || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  const size_t bytes = n * fp_per_elem * 48;
+  return with_staging(c, x, bytes, sgn, n, out, bytes, flags, n,
+                      [&](const uint64_t* dx, const uint64_t* dsgn, uint64_t* o, uint8_t* f) -> int {
+                        bls_launch::witness_sqrt(op, dx, (const uint8_t*)dsgn, o, f, n, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+int bls381_witness_fq_sqrt_batch(bls381_ctx* c, const uint32_t* x, const uint8_t* sgn, uint32_t* sqrt, uint8_t* flags, size_t n) {
+  return witness_sqrt(c, 0, 1, x, sgn, sqrt, flags, n);
+}
+int bls381_witness_fq2_sqrt_batch(bls381_ctx* c, const uint32_t* x, const uint8_t* sgn, uint32_t* sqrt, uint8_t* flags, size_t n) {
+  return witness_sqrt(c, 1, 2, x, sgn, sqrt, flags, n);
+}
+
 int bls381_multi_miller_literal(bls381_ctx* c, uint64_t* out, size_t n) {
   if (!c || (n && !out)) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;

@@ -450,18 +450,17 @@ BLS_HD void fp_store(uint64_t* w, const Fp<L, V>& a, int form) {
   pack384(w, canonical(mul(a, k)));
 }
 
-// Fermat inversion a^(p-2); zero maps to zero (callers test for zero where the reference panics:
-// src/miller_loop_native_optimized.rs:102).  The exponent is a constant, so the 2-bit window walk is
-// wave-uniform control flow: 380 squarings + ~143 multiplications, table of 3 elements.
+// a^e for a compile-time-known exponent given as 6 little-endian u64 words.  The exponent is a constant, so the
+// 2-bit window walk is wave-uniform control flow: ~380 squarings + ~143 multiplications, table of 3 elements.
 template <int L, int V>
-BLS_HD_NOINLINE FpR fp_inv(const Fp<L, V>& a_in) {
+BLS_HD_NOINLINE FpR fp_pow_const(const Fp<L, V>& a_in, const uint64_t (&e)[6]) {
   const FpR a1 = reduce(a_in);
   const FpR a2 = sqr(a1);
   const FpR a3 = mul(a2, a1);
-  FpR r = a1;
+  FpR r = reduce(fp_one());                  // e == 0 -> one
   bool started = false;
-  for (int w = 190; w >= 0; --w) {        // 191 windows cover bits 0..381
-    const uint32_t d = (uint32_t)(BLS_P_MINUS_2[w >> 5] >> ((w & 31) * 2)) & 3u;
+  for (int w = 191; w >= 0; --w) {           // 192 windows cover 384 bits
+    const uint32_t d = (uint32_t)(e[w >> 5] >> ((w & 31) * 2)) & 3u;
     if (started) { r = sqr(r); r = sqr(r); }
     if (d) {
       const FpR t = (d == 1) ? a1 : (d == 2) ? a2 : a3;
@@ -469,6 +468,25 @@ BLS_HD_NOINLINE FpR fp_inv(const Fp<L, V>& a_in) {
     }
   }
   return r;
+}
+
+// Fermat inversion a^(p-2); zero maps to zero (callers test for zero where the reference panics:
+// src/miller_loop_native_optimized.rs:102).
+template <int L, int V>
+BLS_HD FpR fp_inv(const Fp<L, V>& a) { return fp_pow_const(a, BLS_P_MINUS_2); }
+
+// Square-root candidate a^((p+1)/4) (p = 3 mod 4); the caller checks candidate^2 == a.
+template <int L, int V>
+BLS_HD FpR fp_sqrt_candidate(const Fp<L, V>& a) { return fp_pow_const(a, BLS_P_PLUS_1_DIV_4); }
+
+template <int La, int Va, int Lb, int Vb>
+BLS_HD bool fp_eq(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) { return is_zero(sub(a, b)); }
+
+// parity of the canonical representative: sgn0_fq, src/fields/helpers.rs:159-167
+template <int L, int V>
+BLS_HD bool fp_sgn0(const Fp<L, V>& a) {
+  const Fp<1, 1> c = canonical(mul(a, fp_const(BLS_RAW_ONE)));     // leave Montgomery form, then canonicalise
+  return (c.l[0] & 1u) != 0;
 }
 
 }  // namespace bls

@@ -169,4 +169,14 @@ BLS_HD Fp2R fp2_load(const uint64_t* w, int form) { return Fp2R(fp_load(w + 6 * 
 template <int L, int V>
 BLS_HD void fp2_store(uint64_t* w, const Fp2<L, V>& a, int form) { fp_store(w + 6 * lane_part(), a.v, form); }
 
+// both coefficients as Fp values on BOTH lanes of the pair (for Fp-only sub-computations such as norms and roots)
+template <int L, int V> BLS_HD Fp<L, V> coeff0(const Fp2<L, V>& a) { return select(lane_part() == 0, a.v, swap(a.v)); }
+template <int L, int V> BLS_HD Fp<L, V> coeff1(const Fp2<L, V>& a) { return select(lane_part() == 0, swap(a.v), a.v); }
+template <int L0, int V0, int L1, int V1>
+BLS_HD auto fp2_from_coeffs(const Fp<L0, V0>& c0, const Fp<L1, V1>& c1) { return wrap2(sel(lane_part() == 0, c0, c1)); }
+// coefficients stored at two unrelated addresses (MyFq12 / MyFq6 flat orders, src/fields/helpers.rs:39-41)
+BLS_HD Fp2R fp2_load2(const uint64_t* w0, const uint64_t* w1, int form) { return Fp2R(fp_load(lane_part() == 0 ? w0 : w1, form)); }
+template <int L, int V>
+BLS_HD void fp2_store2(uint64_t* w0, uint64_t* w1, const Fp2<L, V>& a, int form) { fp_store(lane_part() == 0 ? w0 : w1, a.v, form); }
+
 }  // namespace bls

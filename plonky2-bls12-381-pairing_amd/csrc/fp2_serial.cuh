@@ -118,4 +118,14 @@ BLS_HD Fp2R fp2_load(const uint64_t* w, int form) { return Fp2R(fp_load(w, form)
 template <int L, int V>
 BLS_HD void fp2_store(uint64_t* w, const Fp2<L, V>& a, int form) { fp_store(w, a.c0, form); fp_store(w + 6, a.c1, form); }
 
+// both coefficients as Fp values usable by this lane (serial: trivially the members)
+template <int L, int V> BLS_HD Fp<L, V> coeff0(const Fp2<L, V>& a) { return a.c0; }
+template <int L, int V> BLS_HD Fp<L, V> coeff1(const Fp2<L, V>& a) { return a.c1; }
+template <int L0, int V0, int L1, int V1>
+BLS_HD auto fp2_from_coeffs(const Fp<L0, V0>& c0, const Fp<L1, V1>& c1) { return make_fp2(c0, c1); }
+// coefficients stored at two unrelated addresses (MyFq12 / MyFq6 flat orders, src/fields/helpers.rs:39-41)
+BLS_HD Fp2R fp2_load2(const uint64_t* w0, const uint64_t* w1, int form) { return Fp2R(fp_load(w0, form), fp_load(w1, form)); }
+template <int L, int V>
+BLS_HD void fp2_store2(uint64_t* w0, uint64_t* w1, const Fp2<L, V>& a, int form) { fp_store(w0, a.c0, form); fp_store(w1, a.c1, form); }
+
 }  // namespace bls

@@ -20,6 +20,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hi
 IO_ARK_MONT, IO_CANONICAL = 0, 1
 OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE = 0, 1, 2
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
+FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
 FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT = range(8)
 FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP = range(7)
 
@@ -34,6 +35,8 @@ SYMBOLS = [
     "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
     "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
     "bls381_debug_line_ref_opt_batch",
+    "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
+    "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
 ]
 
 
@@ -67,6 +70,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_fp12_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    for name in ("bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch"):
+        getattr(lib, name).argtypes = [vp, u32p, u32p, u8p, sz]
+    for name in ("bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch"):
+        getattr(lib, name).argtypes = [vp, u32p, u8p, u32p, u8p, sz]
     # device-pointer twins take raw addresses
     lib.bls381_miller_ref_opt_batch_dev.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.bls381_multi_miller_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
@@ -198,6 +206,50 @@ class Engine:
         self._check(self.lib.bls381_debug_line_ref_opt_batch(self._ctx, pa, pb, pc, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
                     "bls381_debug_line_ref_opt_batch")
         return out
+
+    # witness-generator backend: canonical 12 x u32 digits per Fp -------------------------------
+    def _witness_inverse(self, fn_name, fp_per_elem, x):
+        x = np.ascontiguousarray(x, dtype=np.uint32)
+        n = x.size // (12 * fp_per_elem)
+        assert x.size == n * 12 * fp_per_elem, "ragged input"
+        out = np.zeros_like(x)
+        flags = np.zeros(n, dtype=np.uint8)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        self._check(getattr(self.lib, fn_name)(self._ctx, x.ctypes.data_as(u32p), out.ctypes.data_as(u32p),
+                                               flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), fn_name)
+        return out, flags
+
+    def witness_fq12_inverse(self, x):
+        """Fq12InverseGenerator::run_once (src/fields/fq12_target.rs:351-374), MyFq12 coefficient order."""
+        return self._witness_inverse("bls381_witness_fq12_inverse_batch", 12, x)
+
+    def witness_fq6_inverse(self, x):
+        """Fq6InverseGenerator::run_once (src/fields/fq6_target.rs:395-418), MyFq6 coefficient order."""
+        return self._witness_inverse("bls381_witness_fq6_inverse_batch", 6, x)
+
+    def witness_fq2_inverse(self, x):
+        """Fq2InverseGenerator::run_once (src/fields/fq2_target.rs:331-352): zero maps to zero."""
+        return self._witness_inverse("bls381_witness_fq2_inverse_batch", 2, x)
+
+    def _witness_sqrt(self, fn_name, fp_per_elem, x, sgn):
+        x = np.ascontiguousarray(x, dtype=np.uint32)
+        sgn = np.ascontiguousarray(sgn, dtype=np.uint8)
+        n = x.size // (12 * fp_per_elem)
+        assert x.size == n * 12 * fp_per_elem and sgn.size == n, "ragged input"
+        out = np.zeros_like(x)
+        flags = np.zeros(n, dtype=np.uint8)
+        u32p, u8p = ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)
+        self._check(getattr(self.lib, fn_name)(self._ctx, x.ctypes.data_as(u32p), sgn.ctypes.data_as(u8p), out.ctypes.data_as(u32p),
+                                               flags.ctypes.data_as(u8p), n), fn_name)
+        return out, flags
+
+    def witness_fq_sqrt(self, x, sgn):
+        """FqSqrtGenerator::run_once (src/fields/fq_target.rs:330-343)."""
+        return self._witness_sqrt("bls381_witness_fq_sqrt_batch", 1, x, sgn)
+
+    def witness_fq2_sqrt(self, x, sgn):
+        """Fq2SqrtGenerator::run_once (src/fields/fq2_target.rs:385-410)."""
+        return self._witness_sqrt("bls381_witness_fq2_sqrt_batch", 2, x, sgn)
 
     def multi_miller_loop_literal(self, n):
         """What the reference's multi_miller_loop returns today: Fq12::one() (SURVEY F4)."""

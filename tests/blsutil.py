@@ -186,6 +186,23 @@ class HostSim:
         assert rc == 0
         return out, flags
 
+    def witness_inverse(self, op, x):
+        per = {0: 72, 1: 36, 2: 12}[op]
+        n = len(x) // per
+        out = np.zeros(n * per, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        assert self.lib.hostsim_witness_inverse(op, _ptr(x), _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n)) == 0
+        return out, flags
+
+    def witness_sqrt(self, op, x, sgn):
+        per = {0: 6, 1: 12}[op]
+        n = len(x) // per
+        out = np.zeros(n * per, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        sgn = np.ascontiguousarray(sgn, dtype=np.uint8)
+        assert self.lib.hostsim_witness_sqrt(op, _ptr(x), _ptr(sgn, ctypes.c_uint8), _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n)) == 0
+        return out, flags
+
     def line_ref_opt(self, q1, q2, p, form=IO_ARK_MONT):
         n = len(q1) // 36
         out = np.zeros(n * 24, dtype=np.uint64)

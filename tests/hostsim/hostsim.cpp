@@ -6,6 +6,7 @@
 // The product library has no CPU path: it fails loudly without a GPU.
 #define BLS_BOUND_CHECK 1
 #include "pairing.cuh"
+#include "witness.cuh"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -141,6 +142,27 @@ int hostsim_line_ref_opt(int form, const uint64_t* q1, const uint64_t* q2, const
     const LineND l = line_chord(a, b, pt);
     fp2_store(out + 24 * i, l.n, form);
     fp2_store(out + 24 * i + 12, l.d, form);
+  }
+  return 0;
+}
+
+int hostsim_witness_inverse(int op, const uint64_t* x, uint64_t* out, uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t fl = 0;
+    if (op == 0) { const Fp12R a = fp12_load_my(x + 72 * i); if (is_zero(a)) fl |= WFLAG_NO_INVERSE; fp12_store_my(out + 72 * i, inv(a)); }
+    else if (op == 1) { const Fp6R a = fp6_load_my(x + 36 * i); if (is_zero(a)) fl |= WFLAG_NO_INVERSE; fp6_store_my(out + 36 * i, inv(a)); }
+    else { const Fp2R a = fp2_load(x + 12 * i, IO_CANONICAL); fp2_store(out + 12 * i, inv(a), IO_CANONICAL); }
+    if (flags) flags[i] = fl;
+  }
+  return 0;
+}
+int hostsim_witness_sqrt(int op, const uint64_t* x, const uint8_t* sgn, uint64_t* out, uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t fl = 0;
+    const bool want = (sgn[i] & 1) != 0;
+    if (op == 0) fp_store(out + 6 * i, witness_fq_sqrt(fp_load(x + 6 * i, IO_CANONICAL), want, fl), IO_CANONICAL);
+    else fp2_store(out + 12 * i, witness_fq2_sqrt(fp2_load(x + 12 * i, IO_CANONICAL), want, fl), IO_CANONICAL);
+    if (flags) flags[i] = fl;
   }
   return 0;
 }

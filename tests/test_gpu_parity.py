@@ -229,3 +229,32 @@ def test_device_pointer_api_on_caller_stream(engine, coracle):
     engine.final_exponentiation_dev(mid.data_ptr(), out2.data_ptr(), 0, n)
     engine.sync()
     assert torch.equal(out, out2)
+
+
+def test_witness_generator_backend(engine):
+    """bls381_witness_*: the run_once hooks (fq12/fq6/fq2 inverse, fq/fq2 sqrt with sgn0 fix-up) vs the oracle."""
+    from witness_cases import cases, enc_can, as_u32
+    c = cases(seed=99, n=40)
+    for key, fn, width in (("fq12", engine.witness_fq12_inverse, 12), ("fq6", engine.witness_fq6_inverse, 6)):
+        xs, exp = c[key]
+        out, fl = fn(as_u32(enc_can([v for x in xs for v in x])))
+        got = dec_fps(out.view(np.uint64), IO_CANONICAL)
+        assert [got[width * i:width * (i + 1)] for i in range(len(xs))] == [e[0] for e in exp], key
+        assert list(fl) == [e[1] for e in exp], key
+    xs, exp = c["fq2"]
+    out, fl = engine.witness_fq2_inverse(as_u32(enc_can([v for x in xs for v in x])))
+    got = dec_fps(out.view(np.uint64), IO_CANONICAL)
+    assert [tuple(got[2 * i:2 * i + 2]) for i in range(len(xs))] == [tuple(e) for e in exp] and not fl.any()
+    xs, sg, exp = c["sqrt"]
+    out, fl = engine.witness_fq_sqrt(as_u32(enc_can(xs)), sg)
+    assert dec_fps(out.view(np.uint64), IO_CANONICAL) == [e[0] for e in exp] and list(fl) == [e[1] for e in exp]
+    xs, sg, exp = c["sqrt2"]
+    out, fl = engine.witness_fq2_sqrt(as_u32(enc_can([v for x in xs for v in x])), sg)
+    got = dec_fps(out.view(np.uint64), IO_CANONICAL)
+    assert [tuple(got[2 * i:2 * i + 2]) for i in range(len(xs))] == [tuple(e[0]) for e in exp] and list(fl) == [e[1] for e in exp]
+    # round trip at scale: x * inverse(x) == 1 for 4096 random Fq12 (MyFq12 order in, tree order for the product)
+    rng = random.Random(4)
+    big = [rand_fp12(rng) for _ in range(512)]
+    inv, fl = engine.witness_fq12_inverse(as_u32(enc_can([v for x in big for v in O.fp12_to_myfq12(x)])))
+    invs = [O.myfq12_to_fp12(dec_fps(inv.view(np.uint64)[72 * i:72 * (i + 1)], IO_CANONICAL)) for i in range(len(big))]
+    assert all(O.fp12_is_one(O.fp12_mul(x, y)) for x, y in zip(big[:32], invs[:32])) and not fl.any()

@@ -1,0 +1,33 @@
+"""Witness-generator backend -- device routines compiled for the host vs the oracle."""
+from blsutil import O, dec_fps, IO_CANONICAL
+from witness_cases import cases, enc_can
+
+
+def test_witness_inverses(hostsim):
+    c = cases()
+    for key, op, width in (("fq12", 0, 12), ("fq6", 1, 6), ("fq2", 2, 2)):
+        xs, exp = c[key]
+        out, fl = hostsim.witness_inverse(op, enc_can([v for x in xs for v in x]))
+        got = dec_fps(out, IO_CANONICAL)
+        if key == "fq2":
+            assert [tuple(got[2 * i:2 * i + 2]) for i in range(len(xs))] == [tuple(e) for e in exp]
+            assert not fl.any()
+        else:
+            assert [got[width * i:width * (i + 1)] for i in range(len(xs))] == [e[0] for e in exp], key
+            assert list(fl) == [e[1] for e in exp], key
+
+
+def test_witness_sqrts(hostsim):
+    c = cases()
+    xs, sg, exp = c["sqrt"]
+    out, fl = hostsim.witness_sqrt(0, enc_can(xs), sg)
+    assert dec_fps(out, IO_CANONICAL) == [e[0] for e in exp] and list(fl) == [e[1] for e in exp]
+    assert {e[1] for e in exp} == {0, O.WFLAG_NOT_SQUARE, O.WFLAG_SIGN_UNSATISFIABLE}
+    xs, sg, exp = c["sqrt2"]
+    out, fl = hostsim.witness_sqrt(1, enc_can([v for x in xs for v in x]), sg)
+    got = dec_fps(out, IO_CANONICAL)
+    assert [tuple(got[2 * i:2 * i + 2]) for i in range(len(xs))] == [tuple(e[0]) for e in exp]
+    assert list(fl) == [e[1] for e in exp]
+    for (x, s, (r, f)) in zip(xs, sg, exp):                    # the oracle's roots really are roots with the asked sign
+        if f == 0:
+            assert O.fp2_sqr(r) == (x[0] % O.P, x[1] % O.P) and O.sgn0_fq2(r) == bool(s)
