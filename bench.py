@@ -124,6 +124,16 @@ def main():
         if not ok:
             raise SystemExit("bench: HIP results differ from the oracle -- number would be invalid")
 
+    # HBM traffic per launch from the last committed PMC passes (tools/collect_profile.sh + summarize_profile.py):
+    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, read side x2 (gfx950).
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    if args.workload == "pairing" and n == (1 << 20) and os.path.exists(tpath):
+        try:
+            traffic = float(json.load(open(tpath))["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
+
     if rank == 0:
         total_units = n_units * world * args.steps
         value = total_units / elapsed
@@ -144,7 +154,9 @@ def main():
                        "batch_per_gpu": n_units, "pairs_per_unit": k, "io": "arkworks Montgomery 6xu64 AoS, resident in HBM",
                        "parity_spot_check": ok},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
+                         "algorithmic_bytes_per_launch": bytes_per_unit * n_units,
                          "kernel": "k_multi_miller<%d,%s>" % (k, "true" if args.workload in ("pairing", "groth16") else "false"),
                          "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
                          "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},
