@@ -258,3 +258,38 @@ def test_witness_generator_backend(engine):
     inv, fl = engine.witness_fq12_inverse(as_u32(enc_can([v for x in big for v in O.fp12_to_myfq12(x)])))
     invs = [O.myfq12_to_fp12(dec_fps(inv.view(np.uint64)[72 * i:72 * (i + 1)], IO_CANONICAL)) for i in range(len(big))]
     assert all(O.fp12_is_one(O.fp12_mul(x, y)) for x, y in zip(big[:32], invs[:32])) and not fl.any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 65])
+def test_tiny_and_ragged_batches(engine, coracle, n):
+    """Batches that do not fill a wave (32 pairings per 64-lane wave in the lane-pair layout)."""
+    g1, g2 = synthetic_batch(n, seed=500 + n, jacobian=False, pool=8)
+    out, fl = engine.multi_pairing(g1, g2, 1)
+    exp, efl = coracle.multi(g1, g2, 1, final_exp=True)
+    assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+    j1, j2 = synthetic_batch(n, seed=600 + n, jacobian=True, pool=8)
+    out, fl = engine.optimized_miller_loop(j1, j2)
+    exp, efl = coracle.miller_ref_opt(j1, j2)
+    assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+
+
+def test_unreduced_and_infinity_inputs(engine, coracle):
+    """Field elements >= p are accepted and reduced on load; infinity in any slot of a product skips that pair."""
+    vals = [O.P, O.P + 7, 2 ** 384 - 1, 2 * O.P + 5]
+    a = np.array([(v >> (64 * i)) & (2 ** 64 - 1) for v in vals for i in range(6)], dtype=np.uint64)
+    engine.set_option(B.OPT_IO_FORM, IO_CANONICAL)
+    try:
+        out = dec_fps(engine.fp_op(B.FP_MUL, a, enc_fps([1] * len(vals), IO_CANONICAL)), IO_CANONICAL)
+    finally:
+        engine.set_option(B.OPT_IO_FORM, IO_ARK_MONT)
+    assert out == [v % O.P for v in vals]
+    pairs = random_pairs(8, 321, jacobian=False)
+    for k in (2, 4):
+        terms = [pairs[:k], [(None, pairs[1][1])] + pairs[1:k], [(p, None) for p, q in pairs[:k]]]
+        g1 = enc_fps([c for t in terms for p, q in t for c in flat_g1_aff(p)])
+        g2 = enc_fps([c for t in terms for p, q in t for c in flat_g2_aff(q)])
+        out, fl = engine.multi_pairing(g1, g2, k)
+        exp, efl = coracle.multi(g1, g2, k, final_exp=True)
+        assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+        got = dec_fp12s(out)
+        assert got[0] == O.multi_pairing(terms[0]) and O.fp12_is_one(got[2]) and list(fl) == [0, 2, 2]
