@@ -10,7 +10,8 @@
 // An Fp2 product (a0 + a1 u)(b0 + b1 u) maps onto the pair with no idle lane:
 //     even lane:  c0 = a0*b0 + (-a1)*b1         odd lane:  c1 = a0*b1 + a1*b0
 // i.e. both lanes run  mul2(a0, b_self, +-a1, b_other)  after fetching the partner's coefficients with two DPP
-// quad_perm:[1,0,3,2] moves per limb (full-rate VALU, no LDS).  Squaring is (a0+a1)(a0-a1) on the even lane and
+// quad_perm moves per limb (pair swap [1,0,3,2], pair broadcasts [0,0,2,2] / [1,1,3,3]; full-rate VALU, no
+// LDS).  Squaring is (a0+a1)(a0-a1) on the even lane and
 // (2 a0) a1 on the odd lane: one single-product multiplication each.
 //
 // Formulas: src/fields_as_trees/fq2_target_tree.rs:54-142 (reference).  Same API as fp2_serial.cuh.
@@ -38,6 +39,32 @@ BLS_HD uint32_t dpp_swap(uint32_t x) {
   return x;   // host pass only type-checks this backend; the host simulation uses fp2_serial.cuh
 #endif
 }
+// c0 of the pair on both lanes / c1 of the pair on both lanes: DPP broadcasts inside each lane pair
+BLS_HD uint32_t dpp_bcast0(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xA0 /* quad_perm:[0,0,2,2] */, 0xF, 0xF, true);
+#else
+  return x;
+#endif
+}
+BLS_HD uint32_t dpp_bcast1(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true);
+#else
+  return x;
+#endif
+}
+template <int L, int V>
+BLS_HD Fp<L, V> bcast0(const Fp<L, V>& a) { Fp<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = dpp_bcast0(a.l[i]);
+  return r; }
+template <int L, int V>
+BLS_HD Fp<L, V> bcast1(const Fp<L, V>& a) { Fp<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = dpp_bcast1(a.l[i]);
+  return r; }
+
 template <int L, int V>
 BLS_HD Fp<L, V> swap(const Fp<L, V>& a) {
   Fp<L, V> r;
@@ -94,10 +121,9 @@ template <int La, int Va, int Lb, int Vb>
 BLS_HD Fp2R mul_raw(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   static_assert(Fp2MulFits<La, Va, Lb, Vb>::ok, "fp2 mul: operand bounds too large (fit<> them first)");
   const bool even = lane_part() == 0;
-  const Fp<La, Va> ao = swap(a.v);
   const Fp<Lb, Vb> bo = swap(b.v);
-  const Fp<La, Va> a0 = select(even, a.v, ao);            // a0 on both lanes
-  const Fp<La, Va> a1 = select(even, ao, a.v);            // a1 on both lanes
+  const Fp<La, Va> a0 = bcast0(a.v);                      // a0 on both lanes (one DPP move per limb, no select)
+  const Fp<La, Va> a1 = bcast1(a.v);                      // a1 on both lanes
   const auto a1s = sel(even, neg(a1), a1);                // -a1 (even) / +a1 (odd)
   return Fp2R(mul2(a0, b.v, a1s, bo));                    // even: a0 b0 - a1 b1 ; odd: a0 b1 + a1 b0
 }
@@ -119,7 +145,7 @@ BLS_HD Fp2R sqr(const Fp2<L, V>& a) {
   if constexpr ((2 * L) * (2 * L + 1) <= MONT_LL_MAX && (2 * V) * (2 * V + 1) <= MONT_VV_MAX) {
     const bool even = lane_part() == 0;
     const Fp<L, V> o = swap(a.v);                          // even: a1 ; odd: a0
-    const auto x = add(select(even, a.v, o), o);           // even: a0 + a1 ; odd: a0 + a0
+    const auto x = add(bcast0(a.v), o);                    // even: a0 + a1 ; odd: a0 + a0
     const auto y = sel(even, sub(a.v, o), a.v);            // even: a0 - a1 ; odd: a1
     return Fp2R(mul(x, y));
   } else if constexpr ((2 * V) * (2 * V + 1) > MONT_VV_MAX) {
