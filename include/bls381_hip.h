@@ -62,7 +62,8 @@ enum { BLS381_IO_ARK_MONT = 0, BLS381_IO_CANONICAL = 1 };
 
 /* Fp ops (first-kernel surface).  b may be NULL for unary ops. */
 enum { BLS381_FP_ADD = 0, BLS381_FP_SUB = 1, BLS381_FP_MUL = 2, BLS381_FP_SQR = 3, BLS381_FP_INV = 4,
-       BLS381_FP_NEG = 5, BLS381_FP_TO_MONT = 6, BLS381_FP_FROM_MONT = 7 };
+       BLS381_FP_NEG = 5, BLS381_FP_TO_MONT = 6, BLS381_FP_FROM_MONT = 7,
+       BLS381_FP_DIV = 8 /* a * b^-1 (src/fields/bls12_381base.rs:259-268); b = 0 gives 0 */ };
 /* Fp12 ops */
 enum { BLS381_FP12_MUL = 0, BLS381_FP12_SQR = 1, BLS381_FP12_INV = 2, BLS381_FP12_FROBENIUS = 3,
        BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6 };
@@ -112,6 +113,13 @@ int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_
 /* field-level surfaces */
 int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+/* G2 precomputation: the 68 line-coefficient triples of each point in Miller-loop order
+ * (63 doubling + 5 addition steps; `G2PreparedTarget::from`, src/miller_loop_target.rs:23-76, len == 68 at :69).
+ * g2_aff: n x 2 x 2 x 6, coeffs: n x 68 x 3 x 2 x 6 u64 (19 584 bytes per point; triple = (a, b, c) with
+ * ell(f) = f.mul_by_014(c, b * P.x, a * P.y)).  An infinite input is replaced by the generator and flagged
+ * BLS381_FLAG_INFINITY, as the reference does (:58-60). */
+int bls381_g2_prepare_batch(bls381_ctx* ctx, const uint64_t* g2_aff, uint64_t* coeffs, uint8_t* flags, size_t n);
 
 /* Witness-generator backend: batch forms of the `SimpleGenerator::run_once` hooks through which
  * plonky2 invokes native arithmetic while filling a witness.  Elements are CANONICAL integers as 12 x u32

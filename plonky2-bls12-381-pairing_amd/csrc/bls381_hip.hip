@@ -248,8 +248,8 @@ int bls381_final_exp_batch(bls381_ctx* c, const uint64_t* in, uint64_t* out, uin
 }
 
 int bls381_fp_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  if (!c || op < 0 || op > BLS381_FP_FROM_MONT || (n && (!a || !out))) return BLS381_E_INVALID;
-  if ((op == BLS381_FP_ADD || op == BLS381_FP_SUB || op == BLS381_FP_MUL) && n && !b) return BLS381_E_INVALID;
+  if (!c || op < 0 || op > BLS381_FP_DIV || (n && (!a || !out))) return BLS381_E_INVALID;
+  if ((op == BLS381_FP_ADD || op == BLS381_FP_SUB || op == BLS381_FP_MUL || op == BLS381_FP_DIV) && n && !b) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   return with_staging(c, a, n * 48, b, b ? n * 48 : 0, out, n * 48, nullptr, n,
                       [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
@@ -281,6 +281,17 @@ int bls381_debug_line_ref_opt_batch(bls381_ctx* c, const uint64_t* q1, const uin
   return with_staging(c, q1, n * 288, q2, n * 288, out, n * 192, nullptr, n,
                       [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
                         bls_launch::line_ref_opt(da, db, (const uint64_t*)dp.p, o, n, c->io_form, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+int bls381_g2_prepare_batch(bls381_ctx* c, const uint64_t* g2_aff, uint64_t* coeffs, uint8_t* flags, size_t n) {
+  if (!c || (n && (!g2_aff || !coeffs))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, g2_aff, n * 192, nullptr, 0, coeffs, n * 68 * 288, flags, n,
+                      [&](const uint64_t* dq, const uint64_t*, uint64_t* o, uint8_t* f) -> int {
+                        bls_launch::g2_prepare(dq, o, f, n, c->io_form, c->block, c->stream);
                         HIP_TRY(c, hipGetLastError());
                         return (int)BLS381_OK;
                       });

@@ -34,6 +34,7 @@ k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, 
     case BLS381_FP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
     case BLS381_FP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
     case BLS381_FP_NEG: fp_store(out + 6 * i, neg(x), form); break;
+    case BLS381_FP_DIV: fp_store(out + 6 * i, mul(x, fp_inv(y)), form); break;
     default: break;
   }
 }
@@ -69,6 +70,26 @@ k_line_ref_opt(const uint64_t* __restrict__ q1, const uint64_t* __restrict__ q2,
   fp2_store(out + 24 * i + 12, l.d, form);
 }
 
+// One G2 point per lane (pair): 68 x (a, b, c) Fp2 triples, 19 584 bytes per point.
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_g2_prepare(const uint64_t* __restrict__ g2, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  bool inf;
+  G2Aff q = g2_aff_load(g2 + 24 * i, form, inf);
+  if (inf) {   // the reference substitutes the generator and records the flag (src/miller_loop_target.rs:58-60)
+    q.x = Fp2R(fp2_const(BLS_G2_GEN_X_C0, BLS_G2_GEN_X_C1));
+    q.y = Fp2R(fp2_const(BLS_G2_GEN_Y_C0, BLS_G2_GEN_Y_C1));
+  }
+  uint64_t* o = out + (size_t)68 * 36 * i;
+  g2_prepare(q, [&](int idx, const LineCoeffs& l) {
+    fp2_store(o + 36 * idx, l.a, form);
+    fp2_store(o + 36 * idx + 12, l.b, form);
+    fp2_store(o + 36 * idx + 24, l.c, form);
+  });
+  if (flags && lane_part() == 0) flags[i] = inf ? FLAG_INFINITY : 0;
+}
+
 __global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
@@ -96,6 +117,9 @@ void fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t
 }
 void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
   hipLaunchKernelGGL(k_line_ref_opt, dim3(grid_for(n, block)), dim3(block), 0, s, q1, q2, p, out, n, form);
+}
+void g2_prepare(const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_g2_prepare, dim3(grid_for(n, block)), dim3(block), 0, s, g2, out, flags, n, form);
 }
 void fill_one(uint64_t* out, size_t n, int form, hipStream_t s) {
   hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, s, out, n, form);

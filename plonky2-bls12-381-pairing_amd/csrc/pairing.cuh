@@ -253,6 +253,22 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
   return fit<1, 2>(conj(f));                                              // :111-113 (x < 0)
 }
 
+// G2Prepared: the 68 line-coefficient triples of one G2 point in loop order (63 doubling + 5 addition steps),
+// the precomputation behind `G2PreparedTarget::from` (src/miller_loop_target.rs:23-76; `assert_eq!(coeffs.len(), 68)`
+// at :69).  `emit(index, coeffs)` receives each triple (a, b, c) = (tmp0, tmp3, tmp6) / (t10, t1, t9).
+template <class Emit>
+BLS_HD void g2_prepare(const G2Aff& q, Emit emit) {
+  G2Jac r; r.x = q.x; r.y = q.y; r.z = Fp2R(fp2_one());
+  int idx = 0;
+  for (int b = 61; b >= -1; --b) {
+    const int passes = (b >= 0 && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      const LineCoeffs l = (pass == 0) ? doubling_step(r) : addition_step(r, q);
+      emit(idx++, l);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- I/O
 BLS_HD G1Jac g1_jac_load(const uint64_t* w, int form) {
   G1Jac p; p.x = fp_load(w, form); p.y = fp_load(w + 6, form); p.z = fp_load(w + 12, form); return p;

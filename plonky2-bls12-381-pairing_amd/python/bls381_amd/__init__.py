@@ -21,7 +21,7 @@ IO_ARK_MONT, IO_CANONICAL = 0, 1
 OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE = 0, 1, 2
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
-FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT = range(8)
+FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV = range(9)
 FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP = range(7)
 
 # every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
@@ -34,7 +34,7 @@ SYMBOLS = [
     "bls381_miller_ate_batch", "bls381_pairing_batch",
     "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
     "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
-    "bls381_debug_line_ref_opt_batch",
+    "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
 ]
@@ -70,6 +70,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_fp12_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
+    lib.bls381_g2_prepare_batch.argtypes = [vp, u64p, u64p, u8p, sz]
     u32p = ctypes.POINTER(ctypes.c_uint32)
     for name in ("bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch"):
         getattr(lib, name).argtypes = [vp, u32p, u32p, u8p, sz]
@@ -195,6 +196,17 @@ class Engine:
         self._check(self.lib.bls381_fp12_op_batch(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
                     "bls381_fp12_op_batch")
         return out
+
+    def g2_prepare(self, g2_aff):
+        """68 line-coefficient triples per G2 point (`G2PreparedTarget::from`, src/miller_loop_target.rs:23-76)."""
+        a, pa = _u64(g2_aff)
+        n = a.size // 24
+        assert a.size == n * 24, "ragged input"
+        out = np.zeros(n * 68 * 36, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bls381_g2_prepare_batch(self._ctx, pa, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                     flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_g2_prepare_batch")
+        return out, flags
 
     def line_ref_opt(self, q1_jac, q2_jac, p_jac):
         """Test surface for `optimized_line_function` (opt.rs:8-78): returns n x (n, d) Fp2 pairs."""

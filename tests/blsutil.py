@@ -186,6 +186,12 @@ class HostSim:
         assert rc == 0
         return out, flags
 
+    def g2_prepare(self, g2, form=IO_ARK_MONT):
+        n = len(g2) // 24
+        out = np.zeros(n * 68 * 36, dtype=np.uint64)
+        assert self.lib.hostsim_g2_prepare(form, _ptr(g2), _ptr(out), ctypes.c_size_t(n)) == 0
+        return out
+
     def witness_inverse(self, op, x):
         per = {0: 72, 1: 36, 2: 12}[op]
         n = len(x) // per

@@ -76,6 +76,7 @@ int hostsim_fp_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64
       case OP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
       case OP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
       case OP_NEG: fp_store(out + 6 * i, neg(x), form); break;
+      case 8: fp_store(out + 6 * i, mul(x, fp_inv(y)), form); break;
       default: return 1;
     }
   }
@@ -146,6 +147,16 @@ int hostsim_line_ref_opt(int form, const uint64_t* q1, const uint64_t* q2, const
   return 0;
 }
 
+int hostsim_g2_prepare(int form, const uint64_t* g2, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    bool inf; G2Aff q = g2_aff_load(g2 + 24 * i, form, inf);
+    uint64_t* o = out + (size_t)68 * 36 * i;
+    g2_prepare(q, [&](int idx, const LineCoeffs& l) {
+      fp2_store(o + 36 * idx, l.a, form); fp2_store(o + 36 * idx + 12, l.b, form); fp2_store(o + 36 * idx + 24, l.c, form);
+    });
+  }
+  return 0;
+}
 int hostsim_witness_inverse(int op, const uint64_t* x, uint64_t* out, uint8_t* flags, size_t n) {
   for (size_t i = 0; i < n; ++i) {
     uint8_t fl = 0;

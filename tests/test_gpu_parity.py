@@ -293,3 +293,32 @@ def test_unreduced_and_infinity_inputs(engine, coracle):
         assert np.array_equal(out, exp) and np.array_equal(fl, efl)
         got = dec_fp12s(out)
         assert got[0] == O.multi_pairing(terms[0]) and O.fp12_is_one(got[2]) and list(fl) == [0, 2, 2]
+
+
+def test_g2_prepare_and_fp_div(engine):
+    """bls381_g2_prepare_batch (68 coefficient triples per point) and BLS381_FP_DIV."""
+    pts = [O.G2_GEN, None] + [q for _, q in random_pairs(30, 909, jacobian=False)]
+    out, fl = engine.g2_prepare(enc_fps([c for q in pts for c in flat_g2_aff(q)]))
+    got = dec_fps(out)
+    exp = [v for q in pts for (a, b, c) in O.g2_prepare(q if q is not None else O.G2_GEN) for v in (a[0], a[1], b[0], b[1], c[0], c[1])]
+    assert got == exp and list(fl) == [0, 2] + [0] * 30
+    # the coefficients drive a Miller loop: ell(f) = f.mul_by_014(c, b * P.x, a * P.y) reproduces miller_loop
+    P, Q = O.G1_GEN, O.G2_GEN
+    f = O.FP12_ONE
+    co = O.g2_prepare(Q)
+    it = iter(co)
+    found = False
+    for bbit in range(63, -1, -1):
+        bit = ((O.BLS_X >> 1) >> bbit) & 1
+        if not found:
+            found = bit == 1
+            continue
+        f = O.ell(f, next(it), P)
+        if bit:
+            f = O.ell(f, next(it), P)
+        f = O.fp12_sqr(f)
+    f = O.fp12_conj(O.ell(f, next(it), P))
+    assert f == O.miller_loop(P, Q)
+    rng = random.Random(3)
+    xs = [rand_fp(rng) for _ in range(100)] + [5]; ys = [rand_fp(rng) for _ in range(100)] + [0]
+    assert dec_fps(engine.fp_op(B.FP_DIV, enc_fps(xs), enc_fps(ys))) == [(x * pow(y, O.P - 2, O.P)) % O.P for x, y in zip(xs, ys)]

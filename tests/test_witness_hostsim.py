@@ -31,3 +31,16 @@ def test_witness_sqrts(hostsim):
     for (x, s, (r, f)) in zip(xs, sg, exp):                    # the oracle's roots really are roots with the asked sign
         if f == 0:
             assert O.fp2_sqr(r) == (x[0] % O.P, x[1] % O.P) and O.sgn0_fq2(r) == bool(s)
+
+
+def test_g2_prepare_and_fp_div(hostsim):
+    import random
+    from blsutil import enc_fps, random_pairs, flat_g2_aff, rand_fp
+    pts = [O.G2_GEN] + [q for _, q in random_pairs(3, 808, jacobian=False)]
+    out = dec_fps(hostsim.g2_prepare(enc_fps([c for q in pts for c in flat_g2_aff(q)])))
+    exp = [v for q in pts for (a, b, c) in O.g2_prepare(q) for v in (a[0], a[1], b[0], b[1], c[0], c[1])]
+    assert out == exp and len(out) == len(pts) * 68 * 6
+    rng = random.Random(3)
+    xs = [rand_fp(rng) for _ in range(8)] + [5]; ys = [rand_fp(rng) for _ in range(8)] + [0]
+    got = dec_fps(hostsim.fp_op(8, enc_fps(xs), enc_fps(ys)))
+    assert got == [(x * pow(y, O.P - 2, O.P)) % O.P for x, y in zip(xs, ys)]
