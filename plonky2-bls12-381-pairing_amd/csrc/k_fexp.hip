@@ -1,0 +1,31 @@
+// Kernel translation unit of libbls381_hip.so: the final exponentiation, alone in its file ON PURPOSE.
+// Register budgets propagate through the call graph of a translation unit: the out-of-line tower routines shared
+// with a 512-register kernel would be compiled for 512 registers and drag this kernel back to one wave per SIMD.
+// Here every kernel asks for two waves per SIMD, so the routines are compiled for 256 registers.
+#include <hip/hip_runtime.h>
+#include "../../include/bls381_hip.h"
+#include "pairing.cuh"
+#include "launch.h"
+using namespace bls;
+#ifndef BLS_MAX_BLOCK
+#define BLS_MAX_BLOCK 256
+#endif
+static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
+
+// Final exponentiation, in place allowed (in == out: each lane pair reads its element before writing it).
+// Two waves per SIMD: the cyclotomic-squaring runs need ~250 registers, and with two waves the SIMD issues a MAD
+// every ~4.2 cycles instead of ~5.6 (profiles/r01_v3: 44-46 ms vs 52 ms per 2^18 elements).
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  const Fp12R f = fp12_load(in + 72 * i, form);
+  fp12_store(out + 72 * i, final_exponentiation(f), form);
+  if (flags && lane_part() == 0) flags[i] = 0;
+}
+
+namespace bls_launch {
+void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, block)), dim3(block), 0, s, in, out, flags, n, form);
+}
+}  // namespace bls_launch

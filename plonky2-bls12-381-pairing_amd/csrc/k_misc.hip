@@ -11,15 +11,6 @@ using namespace bls;
 static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
 
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_final_exp(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
-  if (i >= n) return;
-  const Fp12R f = fp12_load(in + 72 * i, form);
-  fp12_store(out + 72 * i, final_exponentiation(f), form);
-  if (flags && lane_part() == 0) flags[i] = 0;
-}
-
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
@@ -105,9 +96,6 @@ bool multi(size_t k, bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* 
     case 4: multi_k4(fe, g1, g2, out, flags, n, form, block, s); return true;
     default: return false;
   }
-}
-void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
-  hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, block)), dim3(block), 0, s, in, out, flags, n, form);
 }
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
   hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);

@@ -276,10 +276,20 @@ BLS_HD_NOINLINE Fp12R cyclotomic_square_call(const Fp12R& a) { return cyclotomic
 // conj(f^|x|), MSB-first square-and-multiply over BLS_X   -- miller_loop.rs:106-126, with the product the
 // reference drops at :121 kept.
 BLS_HD_NOINLINE Fp12R cyclotomic_exp(const Fp12R& f) {
+  // |x| = 0xd201000000010000 has its one bits at 63, 62, 60, 57, 48, 16: after the leading bit the walk is
+  // 1, 2, 3, 9, 32 squarings each followed by a multiplication, then 16 squarings.  Writing it as runs keeps the
+  // hot inner loop down to the cyclotomic squaring alone (small live set); the five multiplications sit outside.
+  static_assert(BLS_X_PARAM == ((1ull << 63) | (1ull << 62) | (1ull << 60) | (1ull << 57) | (1ull << 48) | (1ull << 16)), "run table");
+  constexpr uint64_t RUNS = 1ull | (2ull << 8) | (3ull << 16) | (9ull << 24) | (32ull << 32) | (16ull << 40);   // packed run lengths
   Fp12R tmp = f;                                           // leading one bit
-  for (int b = 62; b >= 0; --b) {
-    tmp = cyclotomic_square(tmp);
-    if ((BLS_X_PARAM >> b) & 1ull) tmp = mul(tmp, f);
+  for (int s = 0; s < 6; ++s) {
+    const int run = (int)((RUNS >> (8 * s)) & 0xffu);
+    for (int i = 0; i < run; ++i) tmp = cyclotomic_square(tmp);
+    // Out of line on purpose: (1) five calls per exponentiation cost nothing, (2) it keeps this function's body
+    // within short-branch range and makes it a non-leaf.  hipcc (ROCm 7.2) relaxes an out-of-range branch in a LEAF
+    // device function through s[30:31] -- the return address -- and the function then never returns
+    // (tools/check_device_asm.py guards the build against that pattern).
+    if (s < 5) tmp = mul_call(tmp, f);
   }
   return fit<1, 2>(conj(tmp));
 }
