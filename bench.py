@@ -157,7 +157,8 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
                          "algorithmic_bytes_per_launch": bytes_per_unit * n_units,
-                         "kernel": "k_multi_miller<%d,%s>" % (k, "true" if args.workload in ("pairing", "groth16") else "false"),
+                         "kernel": ("k_multi_miller<%d,false> + k_final_exp (one step = both launches)" % k) if args.workload in ("pairing", "groth16")
+                                   else ("k_multi_miller<%d,false>" % k if args.workload == "miller" else "k_miller_ref_opt"),
                          "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
                          "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},
         }

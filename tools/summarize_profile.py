@@ -11,12 +11,20 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-def counters(path, kernel_substr="k_multi_miller"):
-    out = {}
+KERNELS = ("k_multi_miller", "k_final_exp")     # one bench step = one launch of each
+
+
+def counters(path):
+    """per-step counter totals: mean over dispatches of each kernel, summed over the kernels of a step"""
+    per = {}
     for r in csv.DictReader(open(path)):
-        if kernel_substr in r["Kernel_Name"]:
-            out.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in out.items()}
+        for kn in KERNELS:
+            if kn in r["Kernel_Name"]:
+                per.setdefault((kn, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    out = {}
+    for (kn, c), v in per.items():
+        out[c] = out.get(c, 0.0) + sum(v) / len(v)
+    return out
 
 for sub, name in (("stats/s_kernel_stats.csv", "kernel_stats.csv"), ("stats/s_kernel_trace.csv", "kernel_trace.csv"),
                   ("fetch/c_counter_collection.csv", "pmc_fetch_size.csv"), ("write/c_counter_collection.csv", "pmc_write_size.csv"),
@@ -29,9 +37,10 @@ fetch = counters(os.path.join(src, "fetch/c_counter_collection.csv"))["FETCH_SIZ
 write = counters(os.path.join(src, "write/c_counter_collection.csv"))["WRITE_SIZE"]
 sq = counters(os.path.join(src, "sq/c_counter_collection.csv"))
 stats = list(csv.DictReader(open(os.path.join(src, "stats/s_kernel_stats.csv"))))
-k = next(r for r in stats if "k_multi_miller" in r["Name"])
+ks = [r for r in stats if any(kn in r["Name"] for kn in KERNELS)]
 summary = {
-    "tag": tag, "kernel": k["Name"].split("(")[0], "rocprof_avg_ms": float(k["AverageNs"]) / 1e6, "calls": int(k["Calls"]),
+    "tag": tag, "kernels": {r["Name"].split("(")[0]: {"avg_ms": float(r["AverageNs"]) / 1e6, "calls": int(r["Calls"])} for r in ks},
+    "rocprof_avg_ms": sum(float(r["AverageNs"]) for r in ks) / 1e6,
     "fetch_size_kib": fetch, "write_size_kib": write,
     "hbm_read_bytes_raw": fetch * 1024, "hbm_read_bytes_corrected_x2": 2 * fetch * 1024, "hbm_write_bytes": write * 1024,
     "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
