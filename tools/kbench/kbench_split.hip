@@ -1,0 +1,75 @@
+// Developer experiment: Miller loop split into (A) G2 line-coefficient precompute and (B) accumulation from
+// coefficients, each with its own occupancy.  Times A and B separately; checksum must equal kbench's Miller-only run.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "pairing.cuh"
+using namespace bls;
+#ifndef KB_ATTR_A
+#define KB_ATTR_A
+#endif
+#ifndef KB_ATTR_B
+#define KB_ATTR_B
+#endif
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+// workspace layout: coeff[(step * n + i) * 36 + {0,12,24}] (u64 words), internal-form limbs stored raw (14 x u32 per Fp
+// would be tighter; the experiment stores the 6 x u64 ABI form to reuse fp2_store/fp2_load)
+__global__ void __launch_bounds__(256) KB_ATTR_A
+k_prep(const uint64_t* __restrict__ g2, uint64_t* __restrict__ ws, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  bool inf; G2Aff q = g2_aff_load(g2 + 24 * i, 0, inf);
+  g2_prepare(q, [&](int idx, const LineCoeffs& l) {
+    uint64_t* o = ws + ((size_t)idx * n + i) * 36;
+    fp2_store(o, l.a, 0); fp2_store(o + 12, l.b, 0); fp2_store(o + 24, l.c, 0);
+  });
+}
+
+__global__ void __launch_bounds__(256) KB_ATTR_B
+k_acc(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ ws, uint64_t* __restrict__ out, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  bool inf; const G1Aff p = g1_aff_load(g1 + 12 * i, 0, inf);
+  Fp12R f = fp12_one();
+  int idx = 0;
+  for (int b = 61; b >= -1; --b) {
+    const bool last = b < 0;
+    const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      const uint64_t* o = ws + ((size_t)idx * n + i) * 36; ++idx;
+      LineCoeffs l; l.a = fp2_load(o, 0); l.b = fp2_load(o + 12, 0); l.c = fp2_load(o + 24, 0);
+      f = ell(f, l, p);
+    }
+    if (!last) f = sqr(f);
+  }
+  fp12_store(out + 72 * i, fit<1, 2>(conj(f)), 0);
+}
+
+int main(int argc, char** argv) {
+  int lg = argc > 1 ? atoi(argv[1]) : 18; int block = argc > 2 ? atoi(argv[2]) : 64;
+  size_t n = (size_t)1 << lg;
+  std::vector<uint64_t> h1(12 * 64), h2(24 * 64);
+  uint64_t s = 0x424C533132333831ull;
+  auto nxt = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (size_t i = 0; i < h1.size(); ++i) { h1[i] = nxt(); if (i % 6 == 5) h1[i] &= 0x0fffffffffffffffull; }
+  for (size_t i = 0; i < h2.size(); ++i) { h2[i] = nxt(); if (i % 6 == 5) h2[i] &= 0x0fffffffffffffffull; }
+  uint64_t *d1, *d2, *dout, *ws;
+  CK(hipMalloc(&d1, n * 96)); CK(hipMalloc(&d2, n * 192)); CK(hipMalloc(&dout, n * 576)); CK(hipMalloc(&ws, n * 68 * 288));
+  for (size_t i = 0; i < n; i += 64) { CK(hipMemcpy(d1 + 12 * i, h1.data(), 96 * 64, hipMemcpyHostToDevice)); CK(hipMemcpy(d2 + 24 * i, h2.data(), 192 * 64, hipMemcpyHostToDevice)); }
+  hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+  unsigned grid = (unsigned)((n * LANES_PER_ELEM + block - 1) / block);
+  float ba = 1e30f, bb = 1e30f;
+  for (int r = 0; r < 3; ++r) {
+    CK(hipEventRecord(e0)); k_prep<<<grid, block>>>(d2, ws, n); CK(hipEventRecord(e1)); k_acc<<<grid, block>>>(d1, ws, dout, n); CK(hipEventRecord(e2));
+    CK(hipEventSynchronize(e2)); float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
+    if (r && a < ba) ba = a; if (r && b < bb) bb = b;
+  }
+  std::vector<uint64_t> ho(72 * 64); CK(hipMemcpy(ho.data(), dout + 72 * (n - 64), 576 * 64, hipMemcpyDeviceToHost));
+  uint64_t x = 0; for (auto v : ho) x = (x * 1099511628211ull) ^ v;
+  hipFuncAttributes fa, fb; CK(hipFuncGetAttributes(&fa, (const void*)k_prep)); CK(hipFuncGetAttributes(&fb, (const void*)k_acc));
+  printf("%-28s n=2^%d  prep %7.3f ms (vgpr %d, scratch %zu)  acc %7.3f ms (vgpr %d, scratch %zu)  total %7.3f ms  checksum=%016llx\n",
+         KB_NAME, lg, ba, fa.numRegs, (size_t)fa.localSizeBytes, bb, fb.numRegs, (size_t)fb.localSizeBytes, ba + bb, (unsigned long long)x);
+  return 0;
+}
