@@ -177,7 +177,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload in ("pairing", "groth16"):
             from blsutil import COracle
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
-            sample = 256 * threads
+            sample = 768 * threads            # ~15 s of CPU work (about 1.2 ms per pairing and core on the GPU box)
             cg1, cg2 = synthetic_batch(sample, jacobian=False, k=k, pool=64)
             orc = COracle()
             orc.multi(cg1[: 12 * k * threads], cg2[: 24 * k * threads], k, final_exp=True, threads=threads)   # warm
