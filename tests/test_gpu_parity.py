@@ -322,3 +322,25 @@ def test_g2_prepare_and_fp_div(engine):
     rng = random.Random(3)
     xs = [rand_fp(rng) for _ in range(100)] + [5]; ys = [rand_fp(rng) for _ in range(100)] + [0]
     assert dec_fps(engine.fp_op(B.FP_DIV, enc_fps(xs), enc_fps(ys))) == [(x * pow(y, O.P - 2, O.P)) % O.P for x, y in zip(xs, ys)]
+
+
+def test_cpp_host_mirror_end_to_end(tmp_path):
+    """plonky2-bls12-381-pairing_amd/host/bls381_pairing.hpp: the reference's names (optimized_miller_loop,
+    multi_miller_loop, MillerLoopResult::final_exponentiation) driven from C++ against the GPU library."""
+    import os, subprocess
+    from blsutil import ROOT
+    exe = tmp_path / "host_mirror_run"
+    libdir = os.path.dirname(B.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", os.path.join(ROOT, "tests", "host_mirror_run.cpp"), "-o", str(exe), "-L", libdir,
+                           "-lbls381_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    (Pj, Qj), = random_pairs(1, 4711, jacobian=True)
+    (Pa, Qa), = random_pairs(1, 4712, jacobian=False)
+    blob = enc_fps(flat_g1_jac(Pj) + flat_g2_jac(Qj) + flat_g1_aff(Pa) + flat_g2_aff(Qa)).tobytes()
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(blob)
+    subprocess.check_call([str(exe), str(inp), str(outp)])
+    out = np.frombuffer(outp.read_bytes(), dtype=np.uint64)
+    got = dec_fp12s(out)
+    assert got[0] == O.optimized_miller_loop(Pj, Qj, False)[0]
+    assert got[1] == O.pairing(Pa, Qa)
+    assert O.fp12_is_one(got[2])
