@@ -63,7 +63,10 @@ enum { BLS381_IO_ARK_MONT = 0, BLS381_IO_CANONICAL = 1 };
 /* Fp ops (first-kernel surface).  b may be NULL for unary ops. */
 enum { BLS381_FP_ADD = 0, BLS381_FP_SUB = 1, BLS381_FP_MUL = 2, BLS381_FP_SQR = 3, BLS381_FP_INV = 4,
        BLS381_FP_NEG = 5, BLS381_FP_TO_MONT = 6, BLS381_FP_FROM_MONT = 7,
-       BLS381_FP_DIV = 8 /* a * b^-1 (src/fields/bls12_381base.rs:259-268); b = 0 gives 0 */ };
+       BLS381_FP_DIV = 8 /* a * b^-1 (src/fields/bls12_381base.rs:259-268); b = 0 gives 0 */,
+       BLS381_FP_LEGENDRE = 9  /* a^((p-1)/2): 0, 1 or p-1 (FqTarget::legendre, src/fields/fq_target.rs:271-274) */,
+       BLS381_FP_IS_SQUARE = 10 /* legendre == 1 -> field element 1, else 0 (fq_target.rs:276-280) */,
+       BLS381_FP_SGN0 = 11      /* parity of the canonical integer as field element 0/1 (sgn0_fq, src/fields/helpers.rs:159-167) */ };
 /* Fp12 ops */
 enum { BLS381_FP12_MUL = 0, BLS381_FP12_SQR = 1, BLS381_FP12_INV = 2, BLS381_FP12_FROBENIUS = 3,
        BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6 };
@@ -113,6 +116,12 @@ int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_
 /* field-level surfaces */
 int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+/* pow_fq (src/fields/helpers.rs:176-195): out[i] = a[i]^exp for one exponent of exp_words (1..8) little-endian u64
+ * words shared by the batch.  Quirks kept: exp == 0 returns a[i] itself; where the exponent's non-adjacent form has
+ * a -1 digit the reference divides by a[i], so a[i] == 0 sets BLS381_FLAG_NO_INVERSE (value 0). */
+int bls381_fp_pow_batch(bls381_ctx* ctx, const uint64_t* a, const uint64_t* exp, size_t exp_words, uint64_t* out,
+                        uint8_t* flags, size_t n);
 
 /* G2 precomputation: the 68 line-coefficient triples of each point in Miller-loop order
  * (63 doubling + 5 addition steps; `G2PreparedTarget::from`, src/miller_loop_target.rs:23-76, len == 68 at :69).

@@ -858,6 +858,64 @@ def sgn0_fq2(x):
     return sgn0_fq(x[0]) or (x[0] % P == 0 and sgn0_fq(x[1]))
 
 
+def get_naf(exp_words):
+    """src/fields/helpers.rs:197-239, literal restatement (exp as little-endian u64 words)."""
+    exp = list(exp_words)
+    ln = len(exp)
+    naf = []
+    for idx in range(ln):
+        e = exp[idx]
+        for _ in range(64):
+            if e & 1:
+                z = 2 - (e % 4)
+                e //= 2
+                if z == -1:
+                    e += 1
+                naf.append(z)
+            else:
+                naf.append(0)
+                e //= 2
+        if e != 0:
+            assert e == 1
+            j = idx + 1
+            while j < len(exp) and exp[j] == 2 ** 64 - 1:
+                exp[j] = 0
+                j += 1
+            if j < len(exp):
+                exp[j] += 1
+            else:
+                exp.append(1)
+    if len(exp) != ln:
+        naf.append(1)
+    return naf
+
+
+def pow_fq(a, exp_words):
+    """src/fields/helpers.rs:176-195 -> (value, flags).  Division by a for -1 digits: a == 0 panics there."""
+    a %= P
+    res, started = a, False
+    for z in reversed(get_naf(exp_words)):
+        if started:
+            res = res * res % P
+        if z != 0:
+            if started:
+                if z == 1:
+                    res = res * a % P
+                else:
+                    if a == 0:
+                        return 0, WFLAG_NO_INVERSE
+                    res = res * pow(a, P - 2, P) % P
+            else:
+                assert z == 1
+                started = True
+    return res, 0
+
+
+def legendre(a):
+    """FqTarget::legendre, src/fields/fq_target.rs:271-274: a^((p-1)/2)."""
+    return pow(a % P, (P - 1) // 2, P)
+
+
 def fp_sqrt_any(x):
     """Some square root of x or None (p = 3 mod 4: x^((p+1)/4))."""
     s = pow(x, (P + 1) // 4, P)

@@ -248,7 +248,7 @@ int bls381_final_exp_batch(bls381_ctx* c, const uint64_t* in, uint64_t* out, uin
 }
 
 int bls381_fp_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  if (!c || op < 0 || op > BLS381_FP_DIV || (n && (!a || !out))) return BLS381_E_INVALID;
+  if (!c || op < 0 || op > BLS381_FP_SGN0 || (n && (!a || !out))) return BLS381_E_INVALID;
   if ((op == BLS381_FP_ADD || op == BLS381_FP_SUB || op == BLS381_FP_MUL || op == BLS381_FP_DIV) && n && !b) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   return with_staging(c, a, n * 48, b, b ? n * 48 : 0, out, n * 48, nullptr, n,
@@ -281,6 +281,17 @@ int bls381_debug_line_ref_opt_batch(bls381_ctx* c, const uint64_t* q1, const uin
   return with_staging(c, q1, n * 288, q2, n * 288, out, n * 192, nullptr, n,
                       [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
                         bls_launch::line_ref_opt(da, db, (const uint64_t*)dp.p, o, n, c->io_form, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+int bls381_fp_pow_batch(bls381_ctx* c, const uint64_t* a, const uint64_t* exp, size_t exp_words, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!c || !exp || exp_words < 1 || exp_words > 8 || (n && (!a || !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, a, n * 48, nullptr, 0, out, n * 48, flags, n,
+                      [&](const uint64_t* da, const uint64_t*, uint64_t* o, uint8_t* f) -> int {
+                        bls_launch::fp_pow(da, exp, (int)exp_words, o, f, n, c->io_form, c->block, c->stream);
                         HIP_TRY(c, hipGetLastError());
                         return (int)BLS381_OK;
                       });

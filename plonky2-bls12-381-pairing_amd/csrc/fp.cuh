@@ -470,6 +470,22 @@ BLS_HD_NOINLINE FpR fp_pow_const(const Fp<L, V>& a_in, const uint64_t (&e)[6]) {
   return r;
 }
 
+// a^e for a run-time exponent of `nwords` little-endian u64 words (wave-uniform: the exponent is a kernel argument),
+// plain MSB-first square-and-multiply.  Value-equivalent to the reference's NAF walk `pow_fq`
+// (src/fields/helpers.rs:176-195), including its quirk that an all-zero exponent returns the base itself.
+template <int L, int V>
+BLS_HD_NOINLINE FpR fp_pow_words(const Fp<L, V>& a_in, const uint64_t* e, int nwords) {
+  const FpR a = reduce(a_in);
+  FpR r = a;
+  bool started = false;
+  for (int b = nwords * 64 - 1; b >= 0; --b) {
+    const bool bit = (e[b >> 6] >> (b & 63)) & 1ull;
+    if (started) r = sqr(r);
+    if (bit) { if (started) r = mul(r, a); else started = true; }
+  }
+  return r;                                  // exponent 0: `res` is never touched and stays a (helpers.rs:177)
+}
+
 // Fermat inversion a^(p-2); zero maps to zero (callers test for zero where the reference panics:
 // src/miller_loop_native_optimized.rs:102).
 template <int L, int V>

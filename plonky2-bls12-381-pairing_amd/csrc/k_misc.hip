@@ -26,6 +26,11 @@ k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, 
     case BLS381_FP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
     case BLS381_FP_NEG: fp_store(out + 6 * i, neg(x), form); break;
     case BLS381_FP_DIV: fp_store(out + 6 * i, mul(x, fp_inv(y)), form); break;
+    case BLS381_FP_LEGENDRE: fp_store(out + 6 * i, fp_pow_const(x, BLS_P_MINUS_1_DIV_2), form); break;
+    case BLS381_FP_IS_SQUARE: {   // legendre == one (fq_target.rs:276-280): zero is not a square by this test
+      const bool sq = fp_eq(fp_pow_const(x, BLS_P_MINUS_1_DIV_2), fp_one());
+      fp_store(out + 6 * i, select(sq, FpR(fp_one()), FpR(fp_zero())), form); break; }
+    case BLS381_FP_SGN0: fp_store(out + 6 * i, select(fp_sgn0(x), FpR(fp_one()), FpR(fp_zero())), form); break;
     default: break;
   }
 }
@@ -81,6 +86,20 @@ k_g2_prepare(const uint64_t* __restrict__ g2, uint64_t* __restrict__ out, uint8_
   if (flags && lane_part() == 0) flags[i] = inf ? FLAG_INFINITY : 0;
 }
 
+struct PowExp { uint64_t w[8]; int nwords; };
+// pow_fq (src/fields/helpers.rs:176-195): a^exp; `has_neg_digit` says the NAF of exp contains a -1, where the
+// reference divides by a and panics for a == 0.
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp_pow(const uint64_t* __restrict__ a, PowExp e, int has_neg_digit, uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  const FpR x = fp_load(a + 6 * i, form);
+  uint8_t fl = 0;
+  if (has_neg_digit && is_zero(x)) fl = 4;       // BLS381_FLAG_NO_INVERSE
+  fp_store(out + 6 * i, fp_pow_words(x, e.w, e.nwords), form);
+  if (flags && lane_part() == 0) flags[i] = fl;
+}
+
 __global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
@@ -108,6 +127,11 @@ void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uin
 }
 void g2_prepare(const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
   hipLaunchKernelGGL(k_g2_prepare, dim3(grid_for(n, block)), dim3(block), 0, s, g2, out, flags, n, form);
+}
+void fp_pow(const uint64_t* a, const uint64_t* exp, int nwords, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  PowExp e; for (int i = 0; i < 8; ++i) e.w[i] = i < nwords ? exp[i] : 0; e.nwords = nwords;
+  int neg = 0; for (int i = 0; i < nwords; ++i) { if (e.w[i] & (e.w[i] >> 1)) neg = 1; if (i + 1 < nwords && (e.w[i] >> 63) && (e.w[i + 1] & 1)) neg = 1; }
+  hipLaunchKernelGGL(k_fp_pow, dim3(grid_for(n, block)), dim3(block), 0, s, a, e, neg, out, flags, n, form);
 }
 void fill_one(uint64_t* out, size_t n, int form, hipStream_t s) {
   hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, s, out, n, form);

@@ -21,7 +21,7 @@ IO_ARK_MONT, IO_CANONICAL = 0, 1
 OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE = 0, 1, 2
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
-FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV = range(9)
+FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV, FP_LEGENDRE, FP_IS_SQUARE, FP_SGN0 = range(12)
 FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP = range(7)
 
 # every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
@@ -34,7 +34,7 @@ SYMBOLS = [
     "bls381_miller_ate_batch", "bls381_pairing_batch",
     "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
     "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
-    "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch",
+    "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch", "bls381_fp_pow_batch",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
 ]
@@ -71,6 +71,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
     lib.bls381_g2_prepare_batch.argtypes = [vp, u64p, u64p, u8p, sz]
+    lib.bls381_fp_pow_batch.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
     u32p = ctypes.POINTER(ctypes.c_uint32)
     for name in ("bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch"):
         getattr(lib, name).argtypes = [vp, u32p, u32p, u8p, sz]
@@ -196,6 +197,19 @@ class Engine:
         self._check(self.lib.bls381_fp12_op_batch(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
                     "bls381_fp12_op_batch")
         return out
+
+    def fp_pow(self, a, exponent: int):
+        """Batch `pow_fq` (src/fields/helpers.rs:176-195): a[i]^exponent, one exponent (< 2^512) for the batch."""
+        a, pa = _u64(a)
+        n = a.size // 6
+        nwords = max(1, (exponent.bit_length() + 63) // 64)
+        e = np.array([(exponent >> (64 * i)) & (2 ** 64 - 1) for i in range(nwords)], dtype=np.uint64)
+        out = np.zeros(n * 6, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bls381_fp_pow_batch(self._ctx, pa, e.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nwords,
+                                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                 flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_fp_pow_batch")
+        return out, flags
 
     def g2_prepare(self, g2_aff):
         """68 line-coefficient triples per G2 point (`G2PreparedTarget::from`, src/miller_loop_target.rs:23-76)."""

@@ -186,6 +186,14 @@ class HostSim:
         assert rc == 0
         return out, flags
 
+    def fp_pow(self, a, exponent, form=IO_ARK_MONT):
+        n = len(a) // 6
+        nwords = max(1, (exponent.bit_length() + 63) // 64)
+        e = np.array([(exponent >> (64 * i)) & (2 ** 64 - 1) for i in range(nwords)], dtype=np.uint64)
+        out = np.zeros(n * 6, dtype=np.uint64)
+        assert self.lib.hostsim_fp_pow(form, _ptr(a), _ptr(e), nwords, _ptr(out), ctypes.c_size_t(n)) == 0
+        return out
+
     def g2_prepare(self, g2, form=IO_ARK_MONT):
         n = len(g2) // 24
         out = np.zeros(n * 68 * 36, dtype=np.uint64)

@@ -77,6 +77,9 @@ int hostsim_fp_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64
       case OP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
       case OP_NEG: fp_store(out + 6 * i, neg(x), form); break;
       case 8: fp_store(out + 6 * i, mul(x, fp_inv(y)), form); break;
+      case 9: fp_store(out + 6 * i, fp_pow_const(x, BLS_P_MINUS_1_DIV_2), form); break;
+      case 10: fp_store(out + 6 * i, select(fp_eq(fp_pow_const(x, BLS_P_MINUS_1_DIV_2), fp_one()), FpR(fp_one()), FpR(fp_zero())), form); break;
+      case 11: fp_store(out + 6 * i, select(fp_sgn0(x), FpR(fp_one()), FpR(fp_zero())), form); break;
       default: return 1;
     }
   }
@@ -147,6 +150,10 @@ int hostsim_line_ref_opt(int form, const uint64_t* q1, const uint64_t* q2, const
   return 0;
 }
 
+int hostsim_fp_pow(int form, const uint64_t* a, const uint64_t* e, int nwords, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) fp_store(out + 6 * i, fp_pow_words(fp_load(a + 6 * i, form), e, nwords), form);
+  return 0;
+}
 int hostsim_g2_prepare(int form, const uint64_t* g2, uint64_t* out, size_t n) {
   for (size_t i = 0; i < n; ++i) {
     bool inf; G2Aff q = g2_aff_load(g2 + 24 * i, form, inf);

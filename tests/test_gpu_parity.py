@@ -344,3 +344,20 @@ def test_cpp_host_mirror_end_to_end(tmp_path):
     assert got[0] == O.optimized_miller_loop(Pj, Qj, False)[0]
     assert got[1] == O.pairing(Pa, Qa)
     assert O.fp12_is_one(got[2])
+
+
+def test_pow_fq_legendre_sgn0(engine):
+    """bls381_fp_pow_batch (pow_fq, helpers.rs:176-195) and the LEGENDRE / IS_SQUARE / SGN0 ops."""
+    from test_witness_hostsim import _pow_cases
+    xs, exps = _pow_cases()
+    a = enc_fps(xs)
+    for e in exps:
+        words = [(e >> (64 * i)) & (2 ** 64 - 1) for i in range(max(1, (e.bit_length() + 63) // 64))]
+        exp = [O.pow_fq(x, words) for x in xs]
+        out, fl = engine.fp_pow(a, e)
+        assert list(fl) == [f for v, f in exp], hex(e)
+        got = dec_fps(out)
+        assert [g for g, (v, f) in zip(got, exp) if f == 0] == [v for v, f in exp if f == 0], hex(e)
+    assert dec_fps(engine.fp_op(B.FP_LEGENDRE, a)) == [O.legendre(x) for x in xs]
+    assert dec_fps(engine.fp_op(B.FP_IS_SQUARE, a)) == [1 if O.legendre(x) == 1 else 0 for x in xs]
+    assert dec_fps(engine.fp_op(B.FP_SGN0, a)) == [1 if O.sgn0_fq(x) else 0 for x in xs]

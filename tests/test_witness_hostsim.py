@@ -44,3 +44,27 @@ def test_g2_prepare_and_fp_div(hostsim):
     xs = [rand_fp(rng) for _ in range(8)] + [5]; ys = [rand_fp(rng) for _ in range(8)] + [0]
     got = dec_fps(hostsim.fp_op(8, enc_fps(xs), enc_fps(ys)))
     assert got == [(x * pow(y, O.P - 2, O.P)) % O.P for x, y in zip(xs, ys)]
+
+
+def _pow_cases():
+    import random
+    rng = random.Random(17)
+    xs = [rng.randrange(1, O.P) for _ in range(6)] + [0, 1, O.P - 1]
+    exps = [0, 1, 2, 3, 0xd201000000010000, (O.P - 1) // 2, O.P - 2, (1 << 128) - 1, 2 ** 200 + 12345]
+    return xs, exps
+
+
+def test_pow_fq_legendre_sgn0(hostsim):
+    from blsutil import enc_fps
+    xs, exps = _pow_cases()
+    a = enc_fps(xs)
+    for e in exps:
+        words = [(e >> (64 * i)) & (2 ** 64 - 1) for i in range(max(1, (e.bit_length() + 63) // 64))]
+        exp = [O.pow_fq(x, words) for x in xs]
+        # the NAF walk equals plain exponentiation (and returns the base for exponent 0)
+        assert [v for v, f in exp if f == 0] == [(x if e == 0 else pow(x, e, O.P)) for x, (v, f) in zip(xs, exp) if f == 0]
+        got = dec_fps(hostsim.fp_pow(a, e))
+        assert got == [v if f == 0 else (x if e == 0 else pow(x, e, O.P)) for x, (v, f) in zip(xs, exp)], hex(e)
+    assert dec_fps(hostsim.fp_op(9, a)) == [O.legendre(x) for x in xs]
+    assert dec_fps(hostsim.fp_op(10, a)) == [1 if O.legendre(x) == 1 else 0 for x in xs]
+    assert dec_fps(hostsim.fp_op(11, a)) == [1 if O.sgn0_fq(x) else 0 for x in xs]
