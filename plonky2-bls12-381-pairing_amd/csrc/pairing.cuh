@@ -1,4 +1,5 @@
-// Curve steps, Miller loops and pairings (one pairing per lane) for the MI355X engine.
+// Curve steps, Miller loops and pairings for the MI355X engine (one pairing per lane pair, or per lane with the
+// serial Fp2 backend).
 //
 // Two loop schedules over the same field kernels:
 //   Mode A  `miller_ref_opt`  bit-exact restatement of the reference's

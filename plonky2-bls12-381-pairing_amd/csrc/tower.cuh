@@ -1,4 +1,5 @@
-// Fp2 -> Fp6 -> Fp12 tower for the MI355X pairing engine (one pairing per lane).
+// Fp6 -> Fp12 tower for the MI355X pairing engine, on top of an Fp2 backend (fp2_pair.cuh: one pairing per lane
+// pair, the GPU default; fp2_serial.cuh: one pairing per lane, used by the host build).
 //
 // Replaces the tower arithmetic the reference takes from ark-ff `Fq2/Fq6/Fq12` [third party]; formulas
 // follow the reference's written statements of the tower:
@@ -6,7 +7,8 @@
 //   Fp6  = Fp2[v]/(v^3-(1+u))   src/fields_as_trees/fq6_target_tree.rs:59-293
 //   Fp12 = Fp6[w]/(w^2-v)       src/fields_as_trees/fq12_target_tree.rs:53-176
 // Field values are canonical at the ABI, so only the algebraic value matters for bit-exactness; inside,
-// every Fp2 product is two fused multiply-pairs with a single Montgomery reduction each (fp.cuh).
+// every Fp2 product is two fused multiply-pairs with a single Montgomery reduction each (fp.cuh) -- one per lane
+// of the pair in the lane-pair layout.
 //
 // Bounds <L, V> (limb / value, see fp.cuh) are carried through every type.  Functions whose results are
 // kept as loop state return "R" types (<1, 2>) by ending in fit<1, 2>().
