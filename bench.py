@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
-    ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16"], default="pairing")
+    ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -84,17 +84,27 @@ def main():
     if args.block:
         eng.set_option(B.OPT_BLOCK_SIZE, args.block)
 
-    k = 3 if args.workload == "groth16" else 1
-    n_units = n // 4 if args.workload == "groth16" else n          # 2^18 proofs x 3 pairs (BASELINE config 4)
+    g16 = args.workload in ("groth16", "groth16_prepared")
+    k = 3 if g16 else 1
+    n_units = n // 4 if g16 else n          # 2^18 proofs x 3 pairs (BASELINE config 4)
     jac = args.workload == "ref_opt"
     g1, g2 = synthetic_batch(n_units, seed=0x424C533132333831 + rank, jacobian=jac, k=k, pool=64)
+    dprep = None
+    if args.workload == "groth16_prepared":
+        # Q1, Q2 fixed for the batch (the verifying key's points): keep Q0 per proof, prepare the other two once
+        g2all = g2.reshape(n_units, 3, 24)
+        prep, _ = eng.g2_prepare(np.ascontiguousarray(g2all[0, 1:3]).reshape(-1))
+        g2 = np.ascontiguousarray(g2all[:, 0]).reshape(-1)
+        dprep = torch.from_numpy(prep.view(np.int64)).to(dev)
     d1 = torch.from_numpy(g1.view(np.int64)).to(dev)
     d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
     dout = torch.empty(n_units * 72, dtype=torch.int64, device=dev)
     dfl = torch.empty(n_units, dtype=torch.uint8, device=dev)
 
     def step():
-        if args.workload in ("pairing", "groth16"):
+        if args.workload == "groth16_prepared":
+            eng.groth16_pairing_dev(d1.data_ptr(), d2.data_ptr(), dprep.data_ptr(), dout.data_ptr(), dfl.data_ptr(), n_units)
+        elif args.workload in ("pairing", "groth16"):
             eng.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), k, dout.data_ptr(), dfl.data_ptr(), n_units)
         elif args.workload == "miller":
             eng.multi_miller_loop_dev(d1.data_ptr(), d2.data_ptr(), k, dout.data_ptr(), dfl.data_ptr(), n_units)
@@ -164,7 +174,8 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
                          "algorithmic_bytes_per_launch": bytes_per_unit * n_units,
-                         "kernel": ("k_multi_miller<%d,false> + k_final_exp (one step = both launches)" % k) if args.workload in ("pairing", "groth16")
+                         "kernel": "k_groth16_miller + k_final_exp" if args.workload == "groth16_prepared" else
+                                   ("k_multi_miller<%d,false> + k_final_exp (one step = both launches)" % k) if args.workload in ("pairing", "groth16")
                                    else ("k_multi_miller<%d,false>" % k if args.workload == "miller" else "k_miller_ref_opt"),
                          "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
                          "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},
@@ -174,7 +185,7 @@ def main():
             line["int_roofline"] = {"bound": "valu_int32_mad", "achieved": macs / 1e12, "peak": INT_MAC_PEAK / 1e12,
                                     "unit": "T limb-MAC/s", "frac": macs / INT_MAC_PEAK,
                                     "fp_mul_per_pairing": FP_MUL_PER_PAIRING, "mac_per_fp_mul": MAC_PER_FP_MUL}
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("pairing", "groth16"):
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("pairing", "groth16"):   # (same value for groth16_prepared)
             from blsutil import COracle
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
             sample = 768 * threads            # ~15 s of CPU work (about 1.2 ms per pairing and core on the GPU box)

@@ -117,6 +117,16 @@ int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_
 int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
+/* Groth16-verify shape with FIXED G2 points (BASELINE config 4): out[i] = e(P0_i, Q0_i) e(P1_i, Q1) e(P2_i, Q2), where
+ * Q1, Q2 are shared by the batch and given as their prepared coefficients -- the output of bls381_g2_prepare_batch for
+ * the two points, 2 x 68 x 3 x 2 x 6 u64 (`G2PreparedTarget`, src/miller_loop_target.rs:23-76).  The coefficients are
+ * staged in LDS once per workgroup; only Q0 pays doubling/addition steps.  Same value as
+ * bls381_multi_pairing_batch(k = 3) on (P0,Q0),(P1,Q1),(P2,Q2).  g1_aff: n x 3 x 2 x 6, g2_var: n x 2 x 2 x 6. */
+int bls381_groth16_pairing_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_var,
+                                 const uint64_t* prepared_fixed, uint64_t* out_gt, uint8_t* flags, size_t n);
+int bls381_groth16_pairing_batch_dev(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_var,
+                                     const uint64_t* prepared_fixed, uint64_t* out_gt, uint8_t* flags, size_t n);
+
 /* pow_fq (src/fields/helpers.rs:176-195): out[i] = a[i]^exp for one exponent of exp_words (1..8) little-endian u64
  * words shared by the batch.  Quirks kept: exp == 0 returns a[i] itself; where the exponent's non-adjacent form has
  * a -1 digit the reference divides by a[i], so a[i] == 0 sets BLS381_FLAG_NO_INVERSE (value 0). */

@@ -286,6 +286,34 @@ int bls381_debug_line_ref_opt_batch(bls381_ctx* c, const uint64_t* q1, const uin
                       });
 }
 
+int bls381_groth16_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                     uint64_t* out_gt, uint8_t* flags, size_t n) {
+  if (!c || (n && (!g1_aff || !g2_var || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  {
+    Timed t(c);
+    bls_launch::groth16(g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return BLS381_OK;
+}
+
+int bls381_groth16_pairing_batch(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                 uint64_t* out_gt, uint8_t* flags, size_t n) {
+  if (!c || (n && (!g1_aff || !g2_var || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DevBuf dprep;
+  const size_t prep_bytes = (size_t)2 * 68 * 288;
+  HIP_TRY(c, hipMalloc(&dprep.p, prep_bytes));
+  HIP_TRY(c, hipMemcpyAsync(dprep.p, prepared_fixed, prep_bytes, hipMemcpyHostToDevice, c->stream));
+  return with_staging(c, g1_aff, n * 3 * 96, g2_var, n * 192, out_gt, n * 576, flags, n,
+                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) -> int {
+                        return bls381_groth16_pairing_batch_dev(c, a, b, (const uint64_t*)dprep.p, o, f, n);
+                      });
+}
+
 int bls381_fp_pow_batch(bls381_ctx* c, const uint64_t* a, const uint64_t* exp, size_t exp_words, uint64_t* out, uint8_t* flags, size_t n) {
   if (!c || !exp || exp_words < 1 || exp_words > 8 || (n && (!a || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;

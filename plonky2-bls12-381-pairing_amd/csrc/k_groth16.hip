@@ -1,0 +1,94 @@
+// Kernel translation unit: Groth16-verify-shaped pairing products with FIXED G2 points (BASELINE config 4;
+// SURVEY.md 7.1 step 8): per proof  e(P0, Q0) * e(P1, Q1) * e(P2, Q2)  where Q1, Q2 (the verifying key's gamma, delta)
+// are the same for the whole batch.  Their 2 x 68 line-coefficient triples (bls381_g2_prepare_batch;
+// `G2PreparedTarget`, src/miller_loop_target.rs:23-76) are converted once per workgroup into the internal limb
+// form and staged in LDS (52 KB), so the Miller loop runs ONE doubling/addition step per iteration (for Q0) instead
+// of three; every lane reads the shared coefficients as LDS broadcasts.
+#include <hip/hip_runtime.h>
+#include "../../include/bls381_hip.h"
+#include "pairing.cuh"
+#include "launch.h"
+using namespace bls;
+
+constexpr int G16_BLOCK = 256;                 // 4 waves share one LDS copy of the coefficients
+constexpr int G16_FIXED = 2;                   // fixed (prepared) pairs
+constexpr int G16_FP_STRIDE = 16;              // dwords per Fp in LDS (14 used; 16 keeps ds_read_b128 aligned)
+constexpr int G16_N_FP = G16_FIXED * 68 * 3 * 2;
+
+BLS_HD FpR lds_fp(const uint32_t* p) {
+  FpR r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = p[i];
+  return r;
+}
+
+__global__ void __launch_bounds__(G16_BLOCK)
+k_groth16_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2_var, const uint64_t* __restrict__ prepared,
+                 uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+  __shared__ __attribute__((aligned(16))) uint32_t coef[G16_N_FP * G16_FP_STRIDE];
+  // stage: ABI form (6 x u64 per Fp) -> internal Montgomery limbs, once per workgroup
+  for (int t = threadIdx.x; t < G16_N_FP; t += G16_BLOCK) {
+    const FpR v = fp_load(prepared + 6 * t, form);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) coef[t * G16_FP_STRIDE + i] = v.l[i];
+  }
+  __syncthreads();
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;                          // after the barrier: every thread took part in the staging
+
+  G1Aff p[3]; bool skip[3]; uint8_t fl = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { bool inf; p[j] = g1_aff_load(g1 + 12 * (3 * i + j), form, inf); skip[j] = inf; }
+  bool qinf;
+  const G2Aff q0 = g2_aff_load(g2_var + 24 * i, form, qinf);
+  skip[0] = skip[0] || qinf;
+  if (skip[0] || skip[1] || skip[2]) fl |= FLAG_INFINITY;
+
+  // coefficient (pair j, step idx, member m in {a,b,c}) component `part` lives at Fp index ((j*68 + idx)*3 + m)*2 + part
+  const int part = (LANES_PER_ELEM == 2) ? lane_part() : 0;
+  auto fixed_line = [&](int j, int idx) {
+    LineCoeffs l;
+    const uint32_t* base = coef + (size_t)(((j * 68 + idx) * 3) * 2) * G16_FP_STRIDE;
+#if BLS_LANES == 2
+    l.a = Fp2R(lds_fp(base + (0 * 2 + part) * G16_FP_STRIDE));
+    l.b = Fp2R(lds_fp(base + (1 * 2 + part) * G16_FP_STRIDE));
+    l.c = Fp2R(lds_fp(base + (2 * 2 + part) * G16_FP_STRIDE));
+#else
+    l.a = Fp2R(lds_fp(base + 0 * G16_FP_STRIDE), lds_fp(base + 1 * G16_FP_STRIDE));
+    l.b = Fp2R(lds_fp(base + 2 * G16_FP_STRIDE), lds_fp(base + 3 * G16_FP_STRIDE));
+    l.c = Fp2R(lds_fp(base + 4 * G16_FP_STRIDE), lds_fp(base + 5 * G16_FP_STRIDE));
+    (void)part;
+#endif
+    return l;
+  };
+
+  G2Jac r; r.x = q0.x; r.y = q0.y; r.z = Fp2R(fp2_one());
+  Fp12R f = fp12_one();
+  int idx = 0;
+  for (int b = 61; b >= -1; --b) {             // same schedule as miller_ate (pairing.cuh)
+    const bool last = b < 0;
+    const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      const LineCoeffs l0 = (pass == 0) ? doubling_step(r) : addition_step(r, q0);
+      if (!skip[0]) f = ell(f, l0, p[0]);
+#pragma unroll
+      for (int j = 0; j < G16_FIXED; ++j) {    // coefficients come from LDS: no curve arithmetic for the fixed points
+        const LineCoeffs lj = fixed_line(j, idx);
+        if (!skip[j + 1]) f = ell(f, lj, p[j + 1]);
+      }
+      ++idx;
+    }
+    if (!last) f = sqr(f);
+  }
+  fp12_store(out + 72 * i, fit<1, 2>(conj(f)), form);
+  if (flags && lane_part() == 0) flags[i] = fl;
+}
+
+namespace bls_launch {
+void groth16(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prepared, uint64_t* out, uint8_t* flags, size_t n,
+             int form, int block, hipStream_t s) {
+  const unsigned grid = (unsigned)((n * bls::LANES_PER_ELEM + G16_BLOCK - 1) / G16_BLOCK);
+  hipLaunchKernelGGL(k_groth16_miller, dim3(grid), dim3(G16_BLOCK), 0, s, g1, g2_var, prepared, out, flags, n, form);
+  final_exp(out, out, nullptr, n, form, block, s);
+}
+}  // namespace bls_launch

@@ -35,6 +35,7 @@ SYMBOLS = [
     "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
     "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
     "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch", "bls381_fp_pow_batch",
+    "bls381_groth16_pairing_batch", "bls381_groth16_pairing_batch_dev",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
 ]
@@ -72,6 +73,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
     lib.bls381_g2_prepare_batch.argtypes = [vp, u64p, u64p, u8p, sz]
     lib.bls381_fp_pow_batch.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
+    lib.bls381_groth16_pairing_batch.argtypes = [vp, u64p, u64p, u64p, u64p, u8p, sz]
+    lib.bls381_groth16_pairing_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     u32p = ctypes.POINTER(ctypes.c_uint32)
     for name in ("bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch"):
         getattr(lib, name).argtypes = [vp, u32p, u32p, u8p, sz]
@@ -210,6 +213,23 @@ class Engine:
                                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                                  flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_fp_pow_batch")
         return out, flags
+
+    def groth16_pairing(self, g1_aff, g2_var, prepared_fixed):
+        """e(P0,Q0) e(P1,Q1) e(P2,Q2) per element with Q1, Q2 fixed for the batch and given as `g2_prepare` output
+        (2 x 68 x 36 u64).  g1_aff: n*36 u64, g2_var: n*24 u64."""
+        a, pa = _u64(g1_aff)
+        b, pb = _u64(g2_var)
+        c, pc = _u64(prepared_fixed)
+        n = a.size // 36
+        assert a.size == n * 36 and b.size == n * 24 and c.size == 2 * 68 * 36, "ragged input"
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bls381_groth16_pairing_batch(self._ctx, pa, pb, pc, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                          flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_groth16_pairing_batch")
+        return out, flags
+
+    def groth16_pairing_dev(self, g1, g2_var, prepared, out, flags, n):
+        self._check(self.lib.bls381_groth16_pairing_batch_dev(self._ctx, g1, g2_var, prepared, out, flags, n), "bls381_groth16_pairing_batch_dev")
 
     def g2_prepare(self, g2_aff):
         """68 line-coefficient triples per G2 point (`G2PreparedTarget::from`, src/miller_loop_target.rs:23-76)."""

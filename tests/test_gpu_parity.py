@@ -361,3 +361,31 @@ def test_pow_fq_legendre_sgn0(engine):
     assert dec_fps(engine.fp_op(B.FP_LEGENDRE, a)) == [O.legendre(x) for x in xs]
     assert dec_fps(engine.fp_op(B.FP_IS_SQUARE, a)) == [1 if O.legendre(x) == 1 else 0 for x in xs]
     assert dec_fps(engine.fp_op(B.FP_SGN0, a)) == [1 if O.sgn0_fq(x) else 0 for x in xs]
+
+
+def test_groth16_fixed_g2_path(engine, coracle):
+    """bls381_groth16_pairing_batch: e(P0,Q0) e(P1,Q1) e(P2,Q2) with Q1, Q2 fixed and staged in LDS as prepared
+    coefficients -- must equal the generic k = 3 product bit for bit (also across infinity cases and ragged sizes)."""
+    n = 300 + 37
+    p1, p2 = random_pairs(2, 1234, jacobian=False)
+    Q1, Q2 = p1[1], p2[1]
+    prep, pfl = engine.g2_prepare(enc_fps(flat_g2_aff(Q1) + flat_g2_aff(Q2)))
+    assert not pfl.any()
+    base = random_pairs(3 * 64, 4321, jacobian=False)
+    proofs = []
+    for i in range(n):
+        P0, Q0 = base[(3 * i) % len(base)]
+        P1 = base[(3 * i + 1) % len(base)][0]
+        P2 = base[(3 * i + 2) % len(base)][0]
+        if i == 5: P1 = None                      # infinity in a fixed slot
+        if i == 6: Q0 = None                      # infinity in the variable slot
+        if i == 7: P0 = P1 = P2 = None            # everything skipped -> one
+        proofs.append((P0, P1, P2, Q0))
+    g1 = enc_fps([c for P0, P1, P2, Q0 in proofs for P in (P0, P1, P2) for c in flat_g1_aff(P)])
+    g2v = enc_fps([c for P0, P1, P2, Q0 in proofs for c in flat_g2_aff(Q0)])
+    out, fl = engine.groth16_pairing(g1, g2v, prep)
+    g2full = enc_fps([c for P0, P1, P2, Q0 in proofs for Q in (Q0, Q1, Q2) for c in flat_g2_aff(Q)])
+    exp, efl = coracle.multi(g1, g2full, 3, final_exp=True, threads=16)
+    assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+    assert np.array_equal(out, engine.multi_pairing(g1, g2full, 3)[0])
+    assert O.fp12_is_one(dec_fp12s(out[7 * 72:8 * 72])[0]) and fl[5] == 2 and fl[6] == 2 and fl[7] == 2
