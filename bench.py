@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
+                    "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -132,6 +134,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_ms = None
+    if args.gather and distributed and args.backend == "nccl":
+        from bls381_amd.sharding import gather_outputs
+        torch.cuda.synchronize(); dist.barrier()
+        g0 = time.perf_counter()
+        full = gather_outputs(dout, n_units * world, 72, dst=0)
+        torch.cuda.synchronize(); dist.barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert full.numel() == n_units * world * 72
+        del full
+
     # spot parity inside the bench: the first 64 results of this rank against the oracle (checker only)
     ok = None
     if rank == 0 and args.workload == "pairing":
@@ -169,7 +183,7 @@ def main():
             "config": {"workload": "batch 2^%d full pairings (Miller loop + Fp12 final exponentiation), 1xMI355X per rank"
                                    % args.batch_log2 if args.workload == "pairing" else args.workload,
                        "batch_per_gpu": n_units, "pairs_per_unit": k, "io": "arkworks Montgomery 6xu64 AoS, resident in HBM",
-                       "parity_spot_check": ok},
+                       "parity_spot_check": ok, "gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
