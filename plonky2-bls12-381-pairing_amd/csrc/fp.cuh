@@ -184,9 +184,8 @@ BLS_HD FpR mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
 
 template <int La, int Va>
 BLS_HD FpR sqr(const Fp<La, Va>& a) {
-  // doubled operand: 2a has limb bound 2 La; cross products 2a_i * a_j
-  static_assert(2 * La * La <= MONT_LL_MAX * 2, "sqr: limb bounds overflow");   // same column total as a*a
-  static_assert(La * La <= MONT_LL_MAX, "sqr: limb bounds overflow");
+  // cross terms use the doubled operand (2 a_i) * a_j once instead of a_i a_j twice: same column total as a * a
+  static_assert(La * La <= MONT_LL_MAX, "sqr: limb bounds overflow the 64-bit column accumulator");
   static_assert(Va * Va <= MONT_VV_MAX, "sqr: value bounds");
   BLS_COUNT(2);
   FpR r = fp_of(montsqr_raw(raw_of(a)));

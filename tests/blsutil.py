@@ -40,10 +40,6 @@ def dec_fps(arr, form=IO_ARK_MONT):
     return [dec_fp(row, form) for row in a]
 
 
-def flat_fp2(a):
-    return [a[0], a[1]]
-
-
 def flat_g1_jac(p):
     return [p[0], p[1], p[2]]
 

@@ -15,7 +15,6 @@ namespace bls {
 
 static long g_checks = 0;
 long g_op_count[8] = {0};
-static int g_max_l_seen = 0;
 
 void bound_check_fail(const char* what) {
   fprintf(stderr, "hostsim: BOUND VIOLATION: %s\n", what);
