@@ -127,6 +127,15 @@ int bls381_groth16_pairing_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const 
 int bls381_groth16_pairing_batch_dev(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_var,
                                      const uint64_t* prepared_fixed, uint64_t* out_gt, uint8_t* flags, size_t n);
 
+/* General form: n_var in {0, 1} pairs with a per-element G2 point followed by n_fixed in {1, 2} pairs whose G2 point is
+ * fixed for the batch (prepared coefficients, n_fixed x 68 x 3 x 2 x 6 u64).  g1_aff: n x (n_var + n_fixed) x 2 x 6 in that
+ * order; g2_var: n x 2 x 2 x 6 (ignored when n_var = 0).  (1, 2) is the Groth16 shape above; (0, 1) pairs many G1 points
+ * against ONE G2 point with no curve arithmetic at all in the Miller loop. */
+int bls381_prepared_pairing_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                  size_t n_var, size_t n_fixed, uint64_t* out_gt, uint8_t* flags, size_t n);
+int bls381_prepared_pairing_batch_dev(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                      size_t n_var, size_t n_fixed, uint64_t* out_gt, uint8_t* flags, size_t n);
+
 /* pow_fq (src/fields/helpers.rs:176-195): out[i] = a[i]^exp for one exponent of exp_words (1..8) little-endian u64
  * words shared by the batch.  Quirks kept: exp == 0 returns a[i] itself; where the exponent's non-adjacent form has
  * a -1 digit the reference divides by a[i], so a[i] == 0 sets BLS381_FLAG_NO_INVERSE (value 0). */

@@ -286,32 +286,43 @@ int bls381_debug_line_ref_opt_batch(bls381_ctx* c, const uint64_t* q1, const uin
                       });
 }
 
-int bls381_groth16_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
-                                     uint64_t* out_gt, uint8_t* flags, size_t n) {
-  if (!c || (n && (!g1_aff || !g2_var || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
+int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                      size_t n_var, size_t n_fixed, uint64_t* out_gt, uint8_t* flags, size_t n) {
+  if (!c || n_var > 1 || n_fixed < 1 || n_fixed > 2 || (n && (!g1_aff || (n_var && !g2_var) || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   {
     Timed t(c);
-    bls_launch::groth16(g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream);
+    if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
+      return BLS381_E_INVALID;
   }
   HIP_TRY(c, hipGetLastError());
   return BLS381_OK;
 }
 
-int bls381_groth16_pairing_batch(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
-                                 uint64_t* out_gt, uint8_t* flags, size_t n) {
-  if (!c || (n && (!g1_aff || !g2_var || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
+int bls381_prepared_pairing_batch(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                  size_t n_var, size_t n_fixed, uint64_t* out_gt, uint8_t* flags, size_t n) {
+  if (!c || n_var > 1 || n_fixed < 1 || n_fixed > 2 || (n && (!g1_aff || (n_var && !g2_var) || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   DevBuf dprep;
-  const size_t prep_bytes = (size_t)2 * 68 * 288;
+  const size_t prep_bytes = n_fixed * 68 * 288;
   HIP_TRY(c, hipMalloc(&dprep.p, prep_bytes));
   HIP_TRY(c, hipMemcpyAsync(dprep.p, prepared_fixed, prep_bytes, hipMemcpyHostToDevice, c->stream));
-  return with_staging(c, g1_aff, n * 3 * 96, g2_var, n * 192, out_gt, n * 576, flags, n,
+  return with_staging(c, g1_aff, n * (n_var + n_fixed) * 96, n_var ? g2_var : nullptr, n_var ? n * 192 : 0, out_gt, n * 576, flags, n,
                       [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) -> int {
-                        return bls381_groth16_pairing_batch_dev(c, a, b, (const uint64_t*)dprep.p, o, f, n);
+                        return bls381_prepared_pairing_batch_dev(c, a, b, (const uint64_t*)dprep.p, n_var, n_fixed, o, f, n);
                       });
+}
+
+int bls381_groth16_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                     uint64_t* out_gt, uint8_t* flags, size_t n) {
+  return bls381_prepared_pairing_batch_dev(c, g1_aff, g2_var, prepared_fixed, 1, 2, out_gt, flags, n);
+}
+
+int bls381_groth16_pairing_batch(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                 uint64_t* out_gt, uint8_t* flags, size_t n) {
+  return bls381_prepared_pairing_batch(c, g1_aff, g2_var, prepared_fixed, 1, 2, out_gt, flags, n);
 }
 
 int bls381_fp_pow_batch(bls381_ctx* c, const uint64_t* a, const uint64_t* exp, size_t exp_words, uint64_t* out, uint8_t* flags, size_t n) {

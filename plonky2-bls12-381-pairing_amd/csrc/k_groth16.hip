@@ -1,4 +1,4 @@
-// Kernel translation unit: Groth16-verify-shaped pairing products with FIXED G2 points (BASELINE config 4;
+// Kernel translation unit: pairing products with FIXED (prepared) G2 points, e.g. the Groth16-verify shape (BASELINE config 4;
 // SURVEY.md 7.1 step 8): per proof  e(P0, Q0) * e(P1, Q1) * e(P2, Q2)  where Q1, Q2 (the verifying key's gamma, delta)
 // are the same for the whole batch.  Their 2 x 68 line-coefficient triples (bls381_g2_prepare_batch;
 // `G2PreparedTarget`, src/miller_loop_target.rs:23-76) are converted once per workgroup into the internal limb
@@ -11,9 +11,8 @@
 using namespace bls;
 
 constexpr int G16_BLOCK = 256;                 // 4 waves share one LDS copy of the coefficients
-constexpr int G16_FIXED = 2;                   // fixed (prepared) pairs
 constexpr int G16_FP_STRIDE = 16;              // dwords per Fp in LDS (14 used; 16 keeps ds_read_b128 aligned)
-constexpr int G16_N_FP = G16_FIXED * 68 * 3 * 2;
+constexpr int G16_FP_PER_POINT = 68 * 3 * 2;   // 68 steps x (a, b, c) x 2 coefficients
 
 BLS_HD FpR lds_fp(const uint32_t* p) {
   FpR r;
@@ -22,9 +21,16 @@ BLS_HD FpR lds_fp(const uint32_t* p) {
   return r;
 }
 
+// NVAR in {0, 1} pairs with a per-element G2 point (full doubling/addition steps), NFIXED in {1, 2} pairs whose G2
+// point is fixed for the batch (prepared coefficients in LDS).  Per element the G1 points come first for the
+// variable pair, then for the fixed pairs.  <1, 2> is the Groth16 shape; <0, 1> is "many P against one Q".
+template <int NVAR, int NFIXED>
 __global__ void __launch_bounds__(G16_BLOCK)
-k_groth16_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2_var, const uint64_t* __restrict__ prepared,
-                 uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2_var, const uint64_t* __restrict__ prepared,
+                  uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
+  constexpr int G16_FIXED = NFIXED;
+  constexpr int G16_N_FP = NFIXED * G16_FP_PER_POINT;
+  constexpr int NP = NVAR + NFIXED;
   __shared__ __attribute__((aligned(16))) uint32_t coef[G16_N_FP * G16_FP_STRIDE];
   // stage: ABI form (6 x u64 per Fp) -> internal Montgomery limbs, once per workgroup
   for (int t = threadIdx.x; t < G16_N_FP; t += G16_BLOCK) {
@@ -36,13 +42,17 @@ k_groth16_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;                          // after the barrier: every thread took part in the staging
 
-  G1Aff p[3]; bool skip[3]; uint8_t fl = 0;
+  G1Aff p[NP]; bool skip[NP]; uint8_t fl = 0;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { bool inf; p[j] = g1_aff_load(g1 + 12 * (3 * i + j), form, inf); skip[j] = inf; }
-  bool qinf;
-  const G2Aff q0 = g2_aff_load(g2_var + 24 * i, form, qinf);
-  skip[0] = skip[0] || qinf;
-  if (skip[0] || skip[1] || skip[2]) fl |= FLAG_INFINITY;
+  for (int j = 0; j < NP; ++j) { bool inf; p[j] = g1_aff_load(g1 + 12 * (NP * i + j), form, inf); skip[j] = inf; }
+  G2Aff q0;
+  if constexpr (NVAR == 1) {
+    bool qinf;
+    q0 = g2_aff_load(g2_var + 24 * i, form, qinf);
+    skip[0] = skip[0] || qinf;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) if (skip[j]) fl |= FLAG_INFINITY;
 
   // coefficient (pair j, step idx, member m in {a,b,c}) component `part` lives at Fp index ((j*68 + idx)*3 + m)*2 + part
   const int part = (LANES_PER_ELEM == 2) ? lane_part() : 0;
@@ -62,19 +72,22 @@ k_groth16_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g
     return l;
   };
 
-  G2Jac r; r.x = q0.x; r.y = q0.y; r.z = Fp2R(fp2_one());
+  G2Jac r;
+  if constexpr (NVAR == 1) { r.x = q0.x; r.y = q0.y; r.z = Fp2R(fp2_one()); }
   Fp12R f = fp12_one();
   int idx = 0;
   for (int b = 61; b >= -1; --b) {             // same schedule as miller_ate (pairing.cuh)
     const bool last = b < 0;
     const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {
-      const LineCoeffs l0 = (pass == 0) ? doubling_step(r) : addition_step(r, q0);
-      if (!skip[0]) f = ell(f, l0, p[0]);
+      if constexpr (NVAR == 1) {
+        const LineCoeffs l0 = (pass == 0) ? doubling_step(r) : addition_step(r, q0);
+        if (!skip[0]) f = ell(f, l0, p[0]);
+      }
 #pragma unroll
       for (int j = 0; j < G16_FIXED; ++j) {    // coefficients come from LDS: no curve arithmetic for the fixed points
         const LineCoeffs lj = fixed_line(j, idx);
-        if (!skip[j + 1]) f = ell(f, lj, p[j + 1]);
+        if (!skip[NVAR + j]) f = ell(f, lj, p[NVAR + j]);
       }
       ++idx;
     }
@@ -85,10 +98,15 @@ k_groth16_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g
 }
 
 namespace bls_launch {
-void groth16(const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prepared, uint64_t* out, uint8_t* flags, size_t n,
-             int form, int block, hipStream_t s) {
-  const unsigned grid = (unsigned)((n * bls::LANES_PER_ELEM + G16_BLOCK - 1) / G16_BLOCK);
-  hipLaunchKernelGGL(k_groth16_miller, dim3(grid), dim3(G16_BLOCK), 0, s, g1, g2_var, prepared, out, flags, n, form);
+bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags,
+              size_t n, int form, int block, hipStream_t s) {
+  const dim3 grid((unsigned)((n * bls::LANES_PER_ELEM + G16_BLOCK - 1) / G16_BLOCK)), blk(G16_BLOCK);
+  if (nvar == 1 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<1, 2>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 0 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<0, 1>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 1 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<1, 1>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 0 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<0, 2>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else return false;
   final_exp(out, out, nullptr, n, form, block, s);
+  return true;
 }
 }  // namespace bls_launch

@@ -36,6 +36,7 @@ SYMBOLS = [
     "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
     "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch", "bls381_fp_pow_batch",
     "bls381_groth16_pairing_batch", "bls381_groth16_pairing_batch_dev",
+    "bls381_prepared_pairing_batch", "bls381_prepared_pairing_batch_dev",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
 ]
@@ -75,6 +76,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_fp_pow_batch.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
     lib.bls381_groth16_pairing_batch.argtypes = [vp, u64p, u64p, u64p, u64p, u8p, sz]
     lib.bls381_groth16_pairing_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
+    lib.bls381_prepared_pairing_batch.argtypes = [vp, u64p, u64p, u64p, sz, sz, u64p, u8p, sz]
+    lib.bls381_prepared_pairing_batch_dev.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp, sz]
     u32p = ctypes.POINTER(ctypes.c_uint32)
     for name in ("bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch"):
         getattr(lib, name).argtypes = [vp, u32p, u32p, u8p, sz]
@@ -227,6 +230,28 @@ class Engine:
         self._check(self.lib.bls381_groth16_pairing_batch(self._ctx, pa, pb, pc, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                                           flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_groth16_pairing_batch")
         return out, flags
+
+    def prepared_pairing(self, g1_aff, g2_var, prepared_fixed, n_var, n_fixed):
+        """Pairing products with n_fixed (1..2) batch-wide fixed G2 points given as `g2_prepare` output and n_var (0..1)
+        per-element G2 points; g1_aff holds n x (n_var + n_fixed) points, variable pair first."""
+        a, pa = _u64(g1_aff)
+        c, pc = _u64(prepared_fixed)
+        n = a.size // (12 * (n_var + n_fixed))
+        pb = None
+        if n_var:
+            b, pb = _u64(g2_var)
+            assert b.size == n * 24, "ragged input"
+        assert a.size == n * 12 * (n_var + n_fixed) and c.size == n_fixed * 68 * 36, "ragged input"
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bls381_prepared_pairing_batch(self._ctx, pa, pb, pc, n_var, n_fixed,
+                                                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                           flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_prepared_pairing_batch")
+        return out, flags
+
+    def prepared_pairing_dev(self, g1, g2_var, prepared, n_var, n_fixed, out, flags, n):
+        self._check(self.lib.bls381_prepared_pairing_batch_dev(self._ctx, g1, g2_var, prepared, n_var, n_fixed, out, flags, n),
+                    "bls381_prepared_pairing_batch_dev")
 
     def groth16_pairing_dev(self, g1, g2_var, prepared, out, flags, n):
         self._check(self.lib.bls381_groth16_pairing_batch_dev(self._ctx, g1, g2_var, prepared, out, flags, n), "bls381_groth16_pairing_batch_dev")

@@ -389,3 +389,25 @@ def test_groth16_fixed_g2_path(engine, coracle):
     assert np.array_equal(out, exp) and np.array_equal(fl, efl)
     assert np.array_equal(out, engine.multi_pairing(g1, g2full, 3)[0])
     assert O.fp12_is_one(dec_fp12s(out[7 * 72:8 * 72])[0]) and fl[5] == 2 and fl[6] == 2 and fl[7] == 2
+
+
+@pytest.mark.parametrize("n_var,n_fixed", [(0, 1), (1, 1), (0, 2)])
+def test_prepared_pairing_shapes(engine, coracle, n_var, n_fixed):
+    """bls381_prepared_pairing_batch: every supported (variable, fixed) shape equals the generic product."""
+    n = 130
+    fixed = [q for _, q in random_pairs(n_fixed, 2222 + n_fixed, jacobian=False)]
+    prep, _ = engine.g2_prepare(enc_fps([c for q in fixed for c in flat_g2_aff(q)]))
+    k = n_var + n_fixed
+    base = random_pairs(k * 32, 3333 + 10 * n_var + n_fixed, jacobian=False)
+    elems = []
+    for i in range(n):
+        ps = [base[(k * i + j) % len(base)][0] for j in range(k)]
+        qs = ([base[(k * i) % len(base)][1]] if n_var else []) + fixed
+        if i == 3: ps[-1] = None
+        elems.append((ps, qs))
+    g1 = enc_fps([c for ps, qs in elems for p in ps for c in flat_g1_aff(p)])
+    g2v = enc_fps([c for ps, qs in elems for c in flat_g2_aff(qs[0])]) if n_var else None
+    out, fl = engine.prepared_pairing(g1, g2v, prep, n_var, n_fixed)
+    g2full = enc_fps([c for ps, qs in elems for q in qs for c in flat_g2_aff(q)])
+    exp, efl = coracle.multi(g1, g2full, k, final_exp=True, threads=16)
+    assert np.array_equal(out, exp) and np.array_equal(fl, efl)
