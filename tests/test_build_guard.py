@@ -1,0 +1,52 @@
+"""tools/check_device_asm.py: the build guard against hipcc relaxing a long branch through the return-address
+register of a leaf device function.  Synthetic assembly for both verdicts, plus the real build."""
+import glob
+import os
+import subprocess
+import sys
+
+from blsutil import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_device_asm as chk  # noqa: E402
+
+BAD = """
+	.amdhsa_kernel my_kernel
+my_kernel:
+	s_getpc_b64 s[30:31]
+	s_setpc_b64 s[30:31]
+	s_endpgm
+_Z4leafv:                               ; @_Z4leafv
+	v_mov_b32_e32 v0, 0
+	s_cbranch_scc0 .LBB1_2
+	s_getpc_b64 s[30:31]
+.Lpost_getpc0:
+	s_add_u32 s30, s30, (.LBB1_3-.Lpost_getpc0)&4294967295
+	s_addc_u32 s31, s31, (.LBB1_3-.Lpost_getpc0)>>32
+	s_setpc_b64 s[30:31]
+.LBB1_2:
+	v_mov_b32_e32 v1, 1
+.LBB1_3:
+	s_setpc_b64 s[30:31]
+"""
+GOOD = BAD.replace("_Z4leafv:                               ; @_Z4leafv\n",
+                   "_Z4leafv:                               ; @_Z4leafv\n\tv_writelane_b32 v40, s30, 0\n\tv_writelane_b32 v40, s31, 1\n")
+
+
+def test_checker_flags_leaf_function_only(tmp_path):
+    bad, good = tmp_path / "bad.s", tmp_path / "good.s"
+    bad.write_text(BAD)
+    good.write_text(GOOD)
+    assert chk.check(str(bad)) == ["_Z4leafv"]          # the kernel with the same pattern is not reported
+    assert chk.check(str(good)) == []
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_device_asm.py"), str(bad)]) == 1
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_device_asm.py"), str(good)]) == 0
+
+
+def test_current_build_is_clean():
+    files = glob.glob(os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "build", "*", "*gfx950.s"))
+    if not files:
+        import pytest
+        pytest.skip("no build directory (library built elsewhere)")
+    for f in files:
+        assert chk.check(f) == [], f
