@@ -67,6 +67,13 @@ enum { BLS381_FP_ADD = 0, BLS381_FP_SUB = 1, BLS381_FP_MUL = 2, BLS381_FP_SQR = 
        BLS381_FP_LEGENDRE = 9  /* a^((p-1)/2): 0, 1 or p-1 (FqTarget::legendre, src/fields/fq_target.rs:271-274) */,
        BLS381_FP_IS_SQUARE = 10 /* legendre == 1 -> field element 1, else 0 (fq_target.rs:276-280) */,
        BLS381_FP_SGN0 = 11      /* parity of the canonical integer as field element 0/1 (sgn0_fq, src/fields/helpers.rs:159-167) */ };
+/* Fp2 ops (src/fields_as_trees/fq2_target_tree.rs:54-142) */
+enum { BLS381_FP2_ADD = 0, BLS381_FP2_SUB = 1, BLS381_FP2_MUL = 2, BLS381_FP2_SQR = 3, BLS381_FP2_INV = 4 /* zero -> zero */,
+       BLS381_FP2_NEG = 5, BLS381_FP2_CONJ = 6, BLS381_FP2_MUL_BY_NONRESIDUE = 7 /* x (1 + u) */ };
+/* Fp6 ops (src/fields_as_trees/fq6_target_tree.rs:59-293).  For MUL_BY_01 / MUL_BY_1 operand b carries the sparse
+ * factor's Fp2 coefficients (c0, c1) / (c1) in its first two / one Fp2 slots, the rest of the slot is ignored. */
+enum { BLS381_FP6_ADD = 0, BLS381_FP6_SUB = 1, BLS381_FP6_MUL = 2, BLS381_FP6_SQR = 3, BLS381_FP6_INV = 4, BLS381_FP6_NEG = 5,
+       BLS381_FP6_MUL_BY_NONRESIDUE = 6 /* x v */, BLS381_FP6_FROBENIUS = 7, BLS381_FP6_MUL_BY_01 = 8, BLS381_FP6_MUL_BY_1 = 9 };
 /* Fp12 ops */
 enum { BLS381_FP12_MUL = 0, BLS381_FP12_SQR = 1, BLS381_FP12_INV = 2, BLS381_FP12_FROBENIUS = 3,
        BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6 };
@@ -115,6 +122,8 @@ int bls381_final_exp_batch_dev(bls381_ctx* ctx, const uint64_t* in_fq12, uint64_
 
 /* field-level surfaces */
 int bls381_fp_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int bls381_fp2_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);   /* n x 2 x 6 */
+int bls381_fp6_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);   /* n x 6 x 6 */
 int bls381_fp12_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
 /* Groth16-verify shape with FIXED G2 points (BASELINE config 4): out[i] = e(P0_i, Q0_i) e(P1_i, Q1) e(P2_i, Q2), where

@@ -259,6 +259,31 @@ int bls381_fp_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t*
                       });
 }
 
+int bls381_fp2_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || op < 0 || op > BLS381_FP2_MUL_BY_NONRESIDUE || (n && (!a || !out))) return BLS381_E_INVALID;
+  if ((op == BLS381_FP2_ADD || op == BLS381_FP2_SUB || op == BLS381_FP2_MUL) && n && !b) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, a, n * 96, b, b ? n * 96 : 0, out, n * 96, nullptr, n,
+                      [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
+                        bls_launch::fp2_op(op, da, db, o, n, c->io_form, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
+int bls381_fp6_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || op < 0 || op > BLS381_FP6_MUL_BY_1 || (n && (!a || !out))) return BLS381_E_INVALID;
+  if ((op == BLS381_FP6_ADD || op == BLS381_FP6_SUB || op == BLS381_FP6_MUL || op == BLS381_FP6_MUL_BY_01 || op == BLS381_FP6_MUL_BY_1) && n && !b)
+    return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  return with_staging(c, a, n * 288, b, b ? n * 288 : 0, out, n * 288, nullptr, n,
+                      [&](const uint64_t* da, const uint64_t* db, uint64_t* o, uint8_t*) -> int {
+                        bls_launch::fp6_op(op, da, db, o, n, c->io_form, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+
 int bls381_fp12_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   if (!c || op < 0 || op > BLS381_FP12_CYCLOTOMIC_EXP || (n && (!a || !out))) return BLS381_E_INVALID;
   if (op == BLS381_FP12_MUL && n && !b) return BLS381_E_INVALID;

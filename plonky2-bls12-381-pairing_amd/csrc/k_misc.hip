@@ -86,6 +86,53 @@ k_g2_prepare(const uint64_t* __restrict__ g2, uint64_t* __restrict__ out, uint8_
   if (flags && lane_part() == 0) flags[i] = inf ? FLAG_INFINITY : 0;
 }
 
+// Fp2 surface (T2: src/fields_as_trees/fq2_target_tree.rs:54-142).  a, b, out: n x 2 x 6 u64
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp2_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  const Fp2R x = fp2_load(a + 12 * i, form);
+  const Fp2R y = b ? fp2_load(b + 12 * i, form) : x;
+  switch (op) {
+    case BLS381_FP2_ADD: fp2_store(out + 12 * i, add(x, y), form); break;
+    case BLS381_FP2_SUB: fp2_store(out + 12 * i, sub(x, y), form); break;
+    case BLS381_FP2_MUL: fp2_store(out + 12 * i, mul(x, y), form); break;
+    case BLS381_FP2_SQR: fp2_store(out + 12 * i, sqr(x), form); break;
+    case BLS381_FP2_INV: fp2_store(out + 12 * i, inv(x), form); break;
+    case BLS381_FP2_NEG: fp2_store(out + 12 * i, neg(x), form); break;
+    case BLS381_FP2_CONJ: fp2_store(out + 12 * i, conj(x), form); break;
+    case BLS381_FP2_MUL_BY_NONRESIDUE: fp2_store(out + 12 * i, mul_xi(x), form); break;
+    default: break;
+  }
+}
+
+BLS_HD Fp6R fp6_load(const uint64_t* w, int form) { return Fp6R(fp2_load(w, form), fp2_load(w + 12, form), fp2_load(w + 24, form)); }
+template <int L, int V>
+BLS_HD void fp6_store(uint64_t* w, const Fp6<L, V>& a, int form) { fp2_store(w, a.c0, form); fp2_store(w + 12, a.c1, form); fp2_store(w + 24, a.c2, form); }
+
+// Fp6 surface (T3: src/fields_as_trees/fq6_target_tree.rs:59-293).  a, out: n x 3 x 2 x 6 u64; b: another Fp6, or for the
+// sparse products the Fp2 coefficients (c0, c1) [MUL_BY_01] / (c1) [MUL_BY_1] packed at the front of an Fp6-sized slot
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_fp6_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  const Fp6R x = fp6_load(a + 36 * i, form);
+  const Fp6R y = b ? fp6_load(b + 36 * i, form) : x;
+  switch (op) {
+    case BLS381_FP6_ADD: fp6_store(out + 36 * i, add(x, y), form); break;
+    case BLS381_FP6_SUB: fp6_store(out + 36 * i, sub(x, y), form); break;
+    case BLS381_FP6_MUL: fp6_store(out + 36 * i, mul(x, y), form); break;
+    case BLS381_FP6_SQR: fp6_store(out + 36 * i, sqr(x), form); break;
+    case BLS381_FP6_INV: fp6_store(out + 36 * i, inv(x), form); break;
+    case BLS381_FP6_NEG: fp6_store(out + 36 * i, neg(x), form); break;
+    case BLS381_FP6_MUL_BY_NONRESIDUE: fp6_store(out + 36 * i, mul_v(x), form); break;
+    case BLS381_FP6_FROBENIUS: fp6_store(out + 36 * i, frobenius(x), form); break;
+    case BLS381_FP6_MUL_BY_01: fp6_store(out + 36 * i, mul_by_01(x, y.c0, y.c1), form); break;
+    case BLS381_FP6_MUL_BY_1: fp6_store(out + 36 * i, mul_by_1(x, y.c0), form); break;
+    default: break;
+  }
+}
+
 struct PowExp { uint64_t w[8]; int nwords; };
 // pow_fq (src/fields/helpers.rs:176-195): a^exp; `has_neg_digit` says the NAF of exp contains a -1, where the
 // reference divides by a and panics for a == 0.
@@ -118,6 +165,12 @@ bool multi(size_t k, bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* 
 }
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
   hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);
+}
+void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_fp2_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);
+}
+void fp6_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
+  hipLaunchKernelGGL(k_fp6_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);
 }
 void fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s) {
   hipLaunchKernelGGL(k_fp12_op, dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, n, form);

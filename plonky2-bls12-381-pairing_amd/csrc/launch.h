@@ -13,6 +13,8 @@ void multi_k3(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, si
 void multi_k4(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
+void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
+void fp6_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fill_one(uint64_t* out, size_t n, int form, hipStream_t s);

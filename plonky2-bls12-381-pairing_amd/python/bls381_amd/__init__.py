@@ -22,6 +22,8 @@ OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE = 0, 1, 2
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
 FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV, FP_LEGENDRE, FP_IS_SQUARE, FP_SGN0 = range(12)
+FP2_ADD, FP2_SUB, FP2_MUL, FP2_SQR, FP2_INV, FP2_NEG, FP2_CONJ, FP2_MUL_BY_NONRESIDUE = range(8)
+FP6_ADD, FP6_SUB, FP6_MUL, FP6_SQR, FP6_INV, FP6_NEG, FP6_MUL_BY_NONRESIDUE, FP6_FROBENIUS, FP6_MUL_BY_01, FP6_MUL_BY_1 = range(10)
 FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP = range(7)
 
 # every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
@@ -33,7 +35,7 @@ SYMBOLS = [
     "bls381_multi_pairing_batch", "bls381_multi_pairing_batch_dev",
     "bls381_miller_ate_batch", "bls381_pairing_batch",
     "bls381_final_exp_batch", "bls381_final_exp_batch_dev",
-    "bls381_fp_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
+    "bls381_fp_op_batch", "bls381_fp2_op_batch", "bls381_fp6_op_batch", "bls381_fp12_op_batch", "bls381_multi_miller_literal",
     "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch", "bls381_fp_pow_batch",
     "bls381_groth16_pairing_batch", "bls381_groth16_pairing_batch_dev",
     "bls381_prepared_pairing_batch", "bls381_prepared_pairing_batch_dev",
@@ -70,6 +72,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_final_exp_batch.argtypes = [vp, u64p, u64p, u8p, sz]
     lib.bls381_fp_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_fp12_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
+    lib.bls381_fp2_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
+    lib.bls381_fp6_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
     lib.bls381_g2_prepare_batch.argtypes = [vp, u64p, u64p, u8p, sz]
@@ -192,6 +196,24 @@ class Engine:
         self._check(self.lib.bls381_fp_op_batch(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n),
                     "bls381_fp_op_batch")
         return out
+
+    def _tower_op(self, fn, name, width, op, a, b):
+        a, pa = _u64(a)
+        pb = None
+        if b is not None:
+            b, pb = _u64(b)
+        n = a.size // width
+        out = np.zeros(n * width, dtype=np.uint64)
+        self._check(fn(self._ctx, op, pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n), name)
+        return out
+
+    def fp2_op(self, op, a, b=None):
+        """Fp2 arithmetic (src/fields_as_trees/fq2_target_tree.rs:54-142) on n x 12 u64."""
+        return self._tower_op(self.lib.bls381_fp2_op_batch, "bls381_fp2_op_batch", 12, op, a, b)
+
+    def fp6_op(self, op, a, b=None):
+        """Fp6 arithmetic (src/fields_as_trees/fq6_target_tree.rs:59-293) on n x 36 u64."""
+        return self._tower_op(self.lib.bls381_fp6_op_batch, "bls381_fp6_op_batch", 36, op, a, b)
 
     def fp12_op(self, op, a, b=None):
         a, pa = _u64(a)

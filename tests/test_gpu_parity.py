@@ -5,7 +5,7 @@ import random
 import numpy as np
 import pytest
 
-from blsutil import (O, enc_fps, dec_fps, enc_fp12s, dec_fp12s, load_golden, hx, rand_fp, rand_fp12, random_pairs,
+from blsutil import (O, enc_fps, dec_fps, enc_fp12s, dec_fp12s, load_golden, hx, rand_fp, rand_fp2, rand_fp12, random_pairs,
                      flat_g1_jac, flat_g2_jac, flat_g1_aff, flat_g2_aff, synthetic_batch, IO_ARK_MONT, IO_CANONICAL)
 import bls381_amd as B
 
@@ -411,3 +411,36 @@ def test_prepared_pairing_shapes(engine, coracle, n_var, n_fixed):
     g2full = enc_fps([c for ps, qs in elems for q in qs for c in flat_g2_aff(q)])
     exp, efl = coracle.multi(g1, g2full, k, final_exp=True, threads=16)
     assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+
+
+def test_fp2_fp6_surfaces(engine):
+    """bls381_fp2_op_batch / bls381_fp6_op_batch against the oracle's tower formulas (T2, T3)."""
+    rng = random.Random(66)
+    n = 70
+    a2 = [rand_fp2(rng) for _ in range(n)] + [(0, 0), (1, 0), (0, 1)]
+    b2 = [rand_fp2(rng) for _ in range(n)] + [(5, 7), (O.P - 1, 3), (O.P - 1, O.P - 1)]
+    A = enc_fps([c for v in a2 for c in v]); Bq = enc_fps([c for v in b2 for c in v])
+    pair = lambda r: [(r[2 * i], r[2 * i + 1]) for i in range(len(r) // 2)]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_ADD, A, Bq))) == [O.fp2_add(x, y) for x, y in zip(a2, b2)]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_SUB, A, Bq))) == [O.fp2_sub(x, y) for x, y in zip(a2, b2)]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_MUL, A, Bq))) == [O.fp2_mul(x, y) for x, y in zip(a2, b2)]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_SQR, A))) == [O.fp2_sqr(x) for x in a2]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_NEG, A))) == [O.fp2_neg(x) for x in a2]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_CONJ, A))) == [O.fp2_conj(x) for x in a2]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_MUL_BY_NONRESIDUE, A))) == [O.fp2_mul_by_nonresidue(x) for x in a2]
+    assert pair(dec_fps(engine.fp2_op(B.FP2_INV, A))) == [O.fp2_inv(x) or (0, 0) for x in a2]
+    a6 = [tuple(rand_fp2(rng) for _ in range(3)) for _ in range(n)] + [O.FP6_ZERO, O.FP6_ONE]
+    b6 = [tuple(rand_fp2(rng) for _ in range(3)) for _ in range(n)] + [O.FP6_ONE, O.FP6_ONE]
+    f6 = lambda xs: enc_fps([c for x in xs for q in x for c in q])
+    d6 = lambda arr: [tuple((r[6 * i + 2 * j], r[6 * i + 2 * j + 1]) for j in range(3)) for r in [dec_fps(arr)] for i in range(len(r) // 6)]
+    A6, B6 = f6(a6), f6(b6)
+    assert d6(engine.fp6_op(B.FP6_ADD, A6, B6)) == [O.fp6_add(x, y) for x, y in zip(a6, b6)]
+    assert d6(engine.fp6_op(B.FP6_SUB, A6, B6)) == [O.fp6_sub(x, y) for x, y in zip(a6, b6)]
+    assert d6(engine.fp6_op(B.FP6_MUL, A6, B6)) == [O.fp6_mul(x, y) for x, y in zip(a6, b6)]
+    assert d6(engine.fp6_op(B.FP6_SQR, A6)) == [O.fp6_sqr(x) for x in a6]
+    assert d6(engine.fp6_op(B.FP6_NEG, A6)) == [O.fp6_neg(x) for x in a6]
+    assert d6(engine.fp6_op(B.FP6_MUL_BY_NONRESIDUE, A6)) == [O.fp6_mul_by_nonresidue(x) for x in a6]
+    assert d6(engine.fp6_op(B.FP6_FROBENIUS, A6)) == [O.fp6_frobenius(x) for x in a6]
+    assert d6(engine.fp6_op(B.FP6_MUL_BY_01, A6, B6)) == [O.fp6_mul_by_01(x, y[0], y[1]) for x, y in zip(a6, b6)]
+    assert d6(engine.fp6_op(B.FP6_MUL_BY_1, A6, B6)) == [O.fp6_mul_by_1(x, y[0]) for x, y in zip(a6, b6)]
+    assert d6(engine.fp6_op(B.FP6_INV, A6)) == [O.fp6_inv(x) or O.FP6_ZERO for x in a6]
