@@ -179,6 +179,11 @@ int bls381_witness_fq_sqrt_batch(bls381_ctx* ctx, const uint32_t* x, const uint8
 /* Fq2SqrtGenerator::run_once, src/fields/fq2_target.rs:385-410 (sgn0_fq2, src/fields/helpers.rs:169-174) */
 int bls381_witness_fq2_sqrt_batch(bls381_ctx* ctx, const uint32_t* x, const uint8_t* sgn, uint32_t* sqrt, uint8_t* flags, size_t n);
 
+/* Coefficient-order helpers, host only (no context, no device): arkworks tree order of the ABI <-> the flat MyFq12 order
+ * of src/fields/helpers.rs:22-76 (coeffs[k] = w^k u^0 part, coeffs[k + 6] = w^k u^1 part).  in != out. */
+void bls381_fq12_ark_to_myfq12(const uint64_t* in, uint64_t* out, size_t n);
+void bls381_fq12_myfq12_to_ark(const uint64_t* in, uint64_t* out, size_t n);
+
 /* Test surface for the private `optimized_line_function` (src/miller_loop_native_optimized.rs:8-78): all three
  * branches, including the vertical one (:62-77) the loop never reaches on subgroup inputs.
  * q1_jac, q2_jac: n x 3 x 2 x 6, p_jac: n x 3 x 6, out_nd: n x (n, d) = n x 2 x 2 x 6. */

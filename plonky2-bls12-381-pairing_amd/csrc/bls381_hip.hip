@@ -411,6 +411,24 @@ int bls381_witness_fq2_sqrt_batch(bls381_ctx* c, const uint32_t* x, const uint8_
   return witness_sqrt(c, 1, 2, x, sgn, sqrt, flags, n);
 }
 
+// Host-side coefficient-order helpers (pure permutations of 48-byte Fp slots, no device work):
+// arkworks tree order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... <-> MyFq12 flat order coeffs[2q + h + 6c]
+// (src/fields/helpers.rs:22-76: coeffs[k] = w^k u^0 part, coeffs[k + 6] = w^k u^1 part).
+void bls381_fq12_ark_to_myfq12(const uint64_t* in, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    for (int h = 0; h < 2; ++h)
+      for (int q = 0; q < 3; ++q)
+        for (int cc = 0; cc < 2; ++cc)
+          std::memcpy(out + 72 * i + 6 * (2 * q + h + 6 * cc), in + 72 * i + 6 * (6 * h + 2 * q + cc), 48);
+}
+void bls381_fq12_myfq12_to_ark(const uint64_t* in, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    for (int h = 0; h < 2; ++h)
+      for (int q = 0; q < 3; ++q)
+        for (int cc = 0; cc < 2; ++cc)
+          std::memcpy(out + 72 * i + 6 * (6 * h + 2 * q + cc), in + 72 * i + 6 * (2 * q + h + 6 * cc), 48);
+}
+
 int bls381_multi_miller_literal(bls381_ctx* c, uint64_t* out, size_t n) {
   if (!c || (n && !out)) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;

@@ -39,6 +39,7 @@ SYMBOLS = [
     "bls381_debug_line_ref_opt_batch", "bls381_g2_prepare_batch", "bls381_fp_pow_batch",
     "bls381_groth16_pairing_batch", "bls381_groth16_pairing_batch_dev",
     "bls381_prepared_pairing_batch", "bls381_prepared_pairing_batch_dev",
+    "bls381_fq12_ark_to_myfq12", "bls381_fq12_myfq12_to_ark",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
 ]
@@ -75,6 +76,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_fp2_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_fp6_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, sz]
     lib.bls381_multi_miller_literal.argtypes = [vp, u64p, sz]
+    for name in ("bls381_fq12_ark_to_myfq12", "bls381_fq12_myfq12_to_ark"):
+        getattr(lib, name).argtypes = [u64p, u64p, sz]
+        getattr(lib, name).restype = None
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
     lib.bls381_g2_prepare_batch.argtypes = [vp, u64p, u64p, u8p, sz]
     lib.bls381_fp_pow_batch.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]

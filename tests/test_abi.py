@@ -64,3 +64,22 @@ def test_cpp_host_mirror_compiles():
         subprocess.check_call(["g++", "-std=c++17", src, "-o", exe, "-L", os.path.dirname(B.LIB_PATH), "-lbls381_hip",
                                "-Wl,-rpath," + os.path.dirname(B.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
         assert subprocess.call([exe]) == 0      # without a GPU the Backend constructor throws PairingError -> exit 0
+
+
+def test_fq12_order_helpers_host_only():
+    """bls381_fq12_ark_to_myfq12 / _myfq12_to_ark are pure host permutations (no GPU): check them against the oracle's
+    statement of the MyFq12 order (src/fields/helpers.rs:22-76) and as inverses of each other."""
+    import random
+    import numpy as np
+    from blsutil import O, enc_fp12s, enc_fps, rand_fp12
+    lib = B.load_library()
+    rng = random.Random(12)
+    xs = [rand_fp12(rng) for _ in range(5)]
+    ark = enc_fp12s(xs)
+    my = np.zeros_like(ark)
+    back = np.zeros_like(ark)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    lib.bls381_fq12_ark_to_myfq12(ark.ctypes.data_as(u64p), my.ctypes.data_as(u64p), len(xs))
+    assert np.array_equal(my, enc_fps([c for x in xs for c in O.fp12_to_myfq12(x)]))
+    lib.bls381_fq12_myfq12_to_ark(my.ctypes.data_as(u64p), back.ctypes.data_as(u64p), len(xs))
+    assert np.array_equal(back, ark)
