@@ -444,3 +444,35 @@ def test_fp2_fp6_surfaces(engine):
     assert d6(engine.fp6_op(B.FP6_MUL_BY_01, A6, B6)) == [O.fp6_mul_by_01(x, y[0], y[1]) for x, y in zip(a6, b6)]
     assert d6(engine.fp6_op(B.FP6_MUL_BY_1, A6, B6)) == [O.fp6_mul_by_1(x, y[0]) for x, y in zip(a6, b6)]
     assert d6(engine.fp6_op(B.FP6_INV, A6)) == [O.fp6_inv(x) or O.FP6_ZERO for x in a6]
+
+
+def test_kat5_reference_fixed_inputs_on_device(engine):
+    """The reference's test_fq6_arithmetic / test_fq12_arithmetic identities on their own fixed limbs, evaluated by the
+    GPU tower (raw limbs fed as canonical integers, like the reference does)."""
+    K = load_golden("reference_kats.json")
+    engine.set_option(B.OPT_IO_FORM, IO_CANONICAL)
+    try:
+        raw = lambda vals: np.array([(v >> (64 * i)) & (2 ** 64 - 1) for v in vals for i in range(6)], dtype=np.uint64)
+        k6 = K["kat5_fq6_inputs"]
+        a, b, c = raw(k6["a"]), raw(k6["b"]), raw(k6["c"])
+        for x in (a, b, c):
+            assert np.array_equal(engine.fp6_op(B.FP6_SQR, x), engine.fp6_op(B.FP6_MUL, x, x))
+        c2 = engine.fp6_op(B.FP6_SQR, c)
+        lhs = engine.fp6_op(B.FP6_MUL, engine.fp6_op(B.FP6_ADD, a, b), c2)
+        rhs = engine.fp6_op(B.FP6_ADD, engine.fp6_op(B.FP6_MUL, c2, a), engine.fp6_op(B.FP6_MUL, c2, b))
+        assert np.array_equal(lhs, rhs)
+        assert dec_fps(c2, IO_CANONICAL) == [v for q in O.fp6_sqr(tuple((k6["c"][2 * i] % O.P, k6["c"][2 * i + 1] % O.P) for i in range(3))) for v in q]
+        k12 = K["kat5_fq12_inputs"]
+        a, b, c = raw(k12["a"]), raw(k12["b"]), raw(k12["c"])
+        sq = lambda x: engine.fp12_op(B.FP12_SQR, x)
+        # Fq12 addition through the Fp6 surface (two halves)
+        add12 = lambda x, y: engine.fp6_op(B.FP6_ADD, x, y)
+        a = add12(sq(sq(a)), c); b = add12(sq(sq(b)), a); c = add12(sq(sq(c)), b)      # :904-914
+        for x in (a, b, c):
+            assert np.array_equal(sq(x), engine.fp12_op(B.FP12_MUL, x, x))
+        c2 = sq(c)
+        lhs = engine.fp12_op(B.FP12_MUL, add12(a, b), c2)
+        rhs = add12(engine.fp12_op(B.FP12_MUL, c2, a), engine.fp12_op(B.FP12_MUL, c2, b))
+        assert np.array_equal(lhs, rhs)
+    finally:
+        engine.set_option(B.OPT_IO_FORM, IO_ARK_MONT)

@@ -104,3 +104,36 @@ def test_golden_files_reproduce():
     for c in load_golden("mode_b.json")["single"][:3]:
         P = tuple(hx(c["g1"])); q = hx(c["g2"]); Q = ((q[0], q[1]), (q[2], q[3]))
         assert O.fp12_flatten(O.pairing(P, Q)) == hx(c["pairing"])
+
+
+def _kat5_values(key, width):
+    k = K[key]
+    red = lambda v: [x % O.P for x in v]          # the reference feeds raw limbs to a canonical-limb type
+    return red(k["a"]), red(k["b"]), red(k["c"]), width
+
+
+def test_kat5_reference_fixed_inputs_fq6():
+    """test_fq6_arithmetic (src/fields_as_trees/fq6_target_tree.rs:392-647) on its own fixed limbs:
+    x^2 == x*x for a, b, c and (a+b) c^2 == c^2 a + c^2 b."""
+    a, b, c, _ = _kat5_values("kat5_fq6_inputs", 6)
+    f6 = lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+    a, b, c = f6(a), f6(b), f6(c)
+    for x in (a, b, c):
+        assert O.fp6_sqr(x) == O.fp6_mul(x, x)
+    c2 = O.fp6_sqr(c)
+    assert O.fp6_mul(O.fp6_add(a, b), c2) == O.fp6_add(O.fp6_mul(c2, a), O.fp6_mul(c2, b))
+
+
+def test_kat5_reference_fixed_inputs_fq12():
+    """test_fq12_arithmetic (src/fields_as_trees/fq12_target_tree.rs:448-942), including its a = a^4 + c,
+    b = b^4 + a, c = c^4 + b preamble (:904-914)."""
+    a, b, c, _ = _kat5_values("kat5_fq12_inputs", 12)
+    a, b, c = O.fp12_unflatten(a), O.fp12_unflatten(b), O.fp12_unflatten(c)
+    add12 = lambda x, y: (O.fp6_add(x[0], y[0]), O.fp6_add(x[1], y[1]))
+    a = add12(O.fp12_sqr(O.fp12_sqr(a)), c)
+    b = add12(O.fp12_sqr(O.fp12_sqr(b)), a)
+    c = add12(O.fp12_sqr(O.fp12_sqr(c)), b)
+    for x in (a, b, c):
+        assert O.fp12_sqr(x) == O.fp12_mul(x, x)
+    c2 = O.fp12_sqr(c)
+    assert O.fp12_mul(add12(a, b), c2) == add12(O.fp12_mul(c2, a), O.fp12_mul(c2, b))

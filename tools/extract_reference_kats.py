@@ -37,6 +37,14 @@ f6 = limb_groups("fields_as_trees/fq6_target_tree.rs", 129, 169)
 f12 = limb_groups("fields_as_trees/fq12_target_tree.rs", 92, 128)
 k["kat4_frobenius_montgomery"] = {"src": "src/fields_as_trees/fq6_target_tree.rs:139-162, fq12_target_tree.rs:101-119",
                                   "frob6_c1_c1": f6[0], "frob6_c2_c0": f6[1], "frob12_c1": f12[0:2]}
+# KAT-5: the fixed limb inputs a, b, c of test_fq6_arithmetic / test_fq12_arithmetic (identities x^2 == x*x and
+# (a+b) c^2 == c^2 a + c^2 b; no expected outputs are stored in the reference)
+g = limb_groups("fields_as_trees/fq6_target_tree.rs", 392, 625)
+assert len(g) == 18, len(g)
+k["kat5_fq6_inputs"] = {"src": "src/fields_as_trees/fq6_target_tree.rs:392-620", "a": g[0:6], "b": g[6:12], "c": g[12:18]}
+g = limb_groups("fields_as_trees/fq12_target_tree.rs", 448, 925)
+assert len(g) == 36, len(g)
+k["kat5_fq12_inputs"] = {"src": "src/fields_as_trees/fq12_target_tree.rs:448-920", "a": g[0:12], "b": g[12:24], "c": g[24:36]}
 # KAT-6: p as u32 digits, loop constants
 txt = open(os.path.join(REF, "fields/bls12_381base.rs")).read().split("\n")[107:113]
 digits = [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]{8}", "\n".join(txt))]
