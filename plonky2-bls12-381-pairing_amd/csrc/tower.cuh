@@ -182,8 +182,8 @@ BLS_FN_FP12 Fp12R mul(const Fp12<La, Va>& a, const Fp12<Lb, Vb>& b) {
   const auto aa = mul(a.c0, b.c0);
   const auto bb = mul(a.c1, b.c1);
   const auto x = mul(fit<1, 64>(add(a.c1, a.c0)), fit<1, 64>(add(b.c0, b.c1)));
-  const auto c1 = sub(sub(x, fit<1, 2>(aa)), fit<1, 2>(bb));
-  const auto c0 = add(mul_v(fit<1, 2>(bb)), fit<1, 2>(aa));
+  const auto c1 = sub(sub(x, aa), bb);          // value bounds stay <= 64: no intermediate reduction needed
+  const auto c0 = add(mul_v(bb), aa);
   return Fp12R(fit<1, 2>(c0), fit<1, 2>(c1));
 }
 
@@ -224,8 +224,8 @@ BLS_FN_FP12 Fp12R frobenius(const Fp12<L, V>& a) {
 // src/miller_loop_native.rs:118-137)
 template <int L, int V, int L0, int V0, int L1, int V1, int L4, int V4>
 BLS_FN_FP12 Fp12R mul_by_014(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const Fp2<L1, V1>& c1, const Fp2<L4, V4>& c4) {
-  const auto aa = fit<1, 2>(mul_by_01(f.c0, c0, c1));
-  const auto bb = fit<1, 2>(mul_by_1(f.c1, c4));
+  const auto aa = mul_by_01(f.c0, c0, c1);
+  const auto bb = mul_by_1(f.c1, c4);
   const auto o = add(c1, c4);
   const auto x = mul_by_01(fit<1, 64>(add(f.c1, f.c0)), c0, o);
   const auto r1 = sub(sub(x, aa), bb);
