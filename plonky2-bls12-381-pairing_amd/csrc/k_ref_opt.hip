@@ -11,7 +11,7 @@ using namespace bls;
 static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
 
 template <bool GENERIC>
-__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_miller_ref_opt(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
                  uint8_t* __restrict__ flags, size_t n, int form) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
