@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fexp-batched-inv", type=int, choices=[0, 1], default=1,
+                    help="1 (library default): batch-wide simultaneous inversion under the final exponentiation; 0: self-contained kernel")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
                     "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -85,6 +87,8 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.block:
         eng.set_option(B.OPT_BLOCK_SIZE, args.block)
+    eng.set_option(B.OPT_FEXP_BATCHED_INVERSION, args.fexp_batched_inv)
+    fexp_kernels = "k_fexp_norm + k_fp_batch_inv + k_final_exp_given" if args.fexp_batched_inv else "k_final_exp"
 
     g16 = args.workload in ("groth16", "groth16_prepared")
     k = 3 if g16 else 1
@@ -188,8 +192,8 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
                          "algorithmic_bytes_per_launch": bytes_per_unit * n_units,
-                         "kernel": "k_groth16_miller + k_final_exp" if args.workload == "groth16_prepared" else
-                                   ("k_multi_miller<%d,false> + k_final_exp (one step = both launches)" % k) if args.workload in ("pairing", "groth16")
+                         "kernel": "k_prepared_miller<1,2> + %s" % fexp_kernels if args.workload == "groth16_prepared" else
+                                   ("k_multi_miller<%d,false> + %s (one step = all of these launches)" % (k, fexp_kernels)) if args.workload in ("pairing", "groth16")
                                    else ("k_multi_miller<%d,false>" % k if args.workload == "miller" else "k_miller_ref_opt"),
                          "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
                          "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},

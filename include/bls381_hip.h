@@ -57,7 +57,11 @@ enum {
   BLS381_FLAG_INFINITY = 2  /* an input point at infinity: pair skipped (result 1 if all pairs skipped) */
 };
 
-enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2 };
+enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
+       /* 1 (default): the one Fp inversion under each final exponentiation (f^-1 of the easy part,
+        * src/fields_as_trees/miller_loop.rs:175) is taken from a batch-wide simultaneous inversion (three launches,
+        * 64 B of context-owned device scratch per element); 0: one self-contained kernel.  Same output bits. */
+       BLS381_OPT_FEXP_BATCHED_INVERSION = 3 };
 enum { BLS381_IO_ARK_MONT = 0, BLS381_IO_CANONICAL = 1 };
 
 /* Fp ops (first-kernel surface).  b may be NULL for unary ops. */

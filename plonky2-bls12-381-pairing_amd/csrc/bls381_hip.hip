@@ -22,6 +22,9 @@ struct bls381_ctx {
   int fp2_shortcut = 0;
   int block = 64;
   int last_hip = 0;
+  int fexp_batched_inv = 1;          // BLS381_OPT_FEXP_BATCHED_INVERSION
+  uint32_t* raw_scratch = nullptr;   // n x 16 dwords: norms / norm inverses between the final-exponentiation kernels
+  size_t raw_scratch_elems = 0;
 };
 
 #define HIP_TRY(ctx, expr)                                        \
@@ -68,6 +71,7 @@ void bls381_destroy(bls381_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->raw_scratch) (void)hipFree(c->raw_scratch);
   delete c;
 }
 
@@ -81,6 +85,7 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
     case BLS381_OPT_BLOCK_SIZE:
       if (value != 64 && value != 128 && value != 256) return BLS381_E_INVALID;
       c->block = value; return BLS381_OK;
+    case BLS381_OPT_FEXP_BATCHED_INVERSION: c->fexp_batched_inv = value ? 1 : 0; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -91,6 +96,7 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_IO_FORM: *value = c->io_form; return BLS381_OK;
     case BLS381_OPT_REF_OPT_FP2_SHORTCUT: *value = c->fp2_shortcut; return BLS381_OK;
     case BLS381_OPT_BLOCK_SIZE: *value = c->block; return BLS381_OK;
+    case BLS381_OPT_FEXP_BATCHED_INVERSION: *value = c->fexp_batched_inv; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -129,6 +135,20 @@ struct Timed {
   ~Timed() { (void)hipEventRecord(c->ev1, c->stream); c->timed = true; }
 };
 
+// Device scratch of the split final exponentiation (grow-only, owned by the context; work queued on the stream that
+// still uses an outgrown buffer is drained before it is released).  *out stays nullptr when the option is off.
+int fexp_scratch(bls381_ctx* c, size_t n, uint32_t** out) {
+  *out = nullptr;
+  if (!c->fexp_batched_inv) return BLS381_OK;
+  if (c->raw_scratch_elems < n) {
+    if (c->raw_scratch) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0; }
+    HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, n * 16 * sizeof(uint32_t)));
+    c->raw_scratch_elems = n;
+  }
+  *out = c->raw_scratch;
+  return BLS381_OK;
+}
+
 int launch_ref_opt(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -144,9 +164,11 @@ template <bool FE>
 int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t* scratch = nullptr;
+  if (FE) { const int rc = fexp_scratch(c, n, &scratch); if (rc != BLS381_OK) return rc; }
   {
     Timed t(c);
-    if (!bls_launch::multi(k, FE, g1, g2, out, flags, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
+    if (!bls_launch::multi(k, FE, g1, g2, out, flags, n, c->io_form, c->block, c->stream, scratch)) return BLS381_E_INVALID;
   }
   HIP_TRY(c, hipGetLastError());
   return BLS381_OK;
@@ -155,9 +177,11 @@ int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k
 int launch_final_exp(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t* scratch = nullptr;
+  { const int rc = fexp_scratch(c, n, &scratch); if (rc != BLS381_OK) return rc; }
   {
     Timed t(c);
-    bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream);
+    bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream, scratch);
   }
   HIP_TRY(c, hipGetLastError());
   return BLS381_OK;
@@ -316,9 +340,11 @@ int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, con
   if (!c || n_var > 1 || n_fixed < 1 || n_fixed > 2 || (n && (!g1_aff || (n_var && !g2_var) || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t* scratch = nullptr;
+  { const int rc = fexp_scratch(c, n, &scratch); if (rc != BLS381_OK) return rc; }
   {
     Timed t(c);
-    if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
+    if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream, scratch))
       return BLS381_E_INVALID;
   }
   HIP_TRY(c, hipGetLastError());

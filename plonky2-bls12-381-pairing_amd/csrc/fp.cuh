@@ -490,6 +490,42 @@ BLS_HD_NOINLINE FpR fp_pow_words(const Fp<L, V>& a_in, const uint64_t* e, int nw
 template <int L, int V>
 BLS_HD FpR fp_inv(const Fp<L, V>& a) { return fp_pow_const(a, BLS_P_MINUS_2); }
 
+// Simultaneous inversion (Montgomery's trick) of N values held by ONE lane: 3 N multiplications and a single
+// fp_inv.  Zeros stay zero and do not disturb their neighbours.  Used to amortise the one Fp inversion under every
+// final exponentiation across elements (k_fp_batch_inv, k_misc.hip).
+template <int N>
+BLS_HD void fp_batch_inv(FpR (&x)[N]) {
+  FpR pre[N];                                  // pre[i] = x_0 ... x_(i-1), zeros read as one
+  bool z[N];
+  FpR acc = FpR(fp_one());
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    z[i] = is_zero(x[i]);
+    x[i] = select(z[i], FpR(fp_one()), x[i]);
+    pre[i] = acc;
+    acc = mul(acc, x[i]);
+  }
+  FpR inv = fp_inv(acc);                       // (x_0 ... x_(N-1))^-1
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    const FpR o = mul(inv, pre[i]);            // x_i^-1
+    inv = mul(inv, x[i]);
+    x[i] = select(z[i], FpR(fp_zero()), o);
+  }
+}
+
+// Internal-form Fp values parked in device scratch between kernels: the 14 limbs as they are (normalised, value < 2p),
+// 16 dwords apart so that the accesses are four aligned dwordx4.
+constexpr int RAW_FP_STRIDE = 16;
+BLS_HD FpR raw_fp_load(const uint32_t* p) { FpR r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = p[i];
+  return r; }
+BLS_HD void raw_fp_store(uint32_t* p, const FpR& a) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) p[i] = a.l[i];
+}
+
 // Square-root candidate a^((p+1)/4) (p = 3 mod 4); the caller checks candidate^2 == a.
 template <int L, int V>
 BLS_HD FpR fp_sqrt_candidate(const Fp<L, V>& a) { return fp_pow_const(a, BLS_P_PLUS_1_DIV_4); }

@@ -168,14 +168,22 @@ BLS_HD auto mul_xi(const Fp2<L, V>& a) {
   return wrap2(sel(lane_part() == 0, sub(a.v, o), add(a.v, o)));
 }
 
+// norm a0^2 + a1^2 (an Fp value, identical on both lanes) and the inverse conj(a) / norm given 1 / norm: the two halves
+// of fq2_target_tree.rs:66-78, split so that the one Fp inversion underneath can be batched across elements
+// (final exponentiation, k_fexp.hip).
+BLS_HD FpR fp2_norm(const Fp2R& a) {
+  const FpR o = swap(a.v);
+  return mul2(a.v, a.v, o, o);
+}
+BLS_HD Fp2R fp2_inv_given(const Fp2R& a, const FpR& norm_inv) {
+  return Fp2R(mul(sel(lane_part() == 0, a.v, neg(a.v)), norm_inv));
+}
+
 // inverse via the norm; both lanes compute the (identical) Fp inverse.  Zero maps to zero.
 template <int L, int V>
 BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
   const Fp2R a = fit<1, 2>(a_in);
-  const FpR o = swap(a.v);
-  const FpR n = mul2(a.v, a.v, o, o);
-  const FpR ni = fp_inv(n);
-  return Fp2R(mul(sel(lane_part() == 0, a.v, neg(a.v)), ni));
+  return fp2_inv_given(a, fp_inv(fp2_norm(a)));
 }
 
 // pair-wide AND of a per-lane predicate

@@ -95,13 +95,15 @@ BLS_HD auto conj(const Fp2<L, V>& a) { return make_fp2(a.c0, neg(a.c1)); }   // 
 template <int L, int V>
 BLS_HD auto mul_xi(const Fp2<L, V>& a) { return make_fp2(sub(a.c0, a.c1), add(a.c0, a.c1)); }
 
+// norm a0^2 + a1^2 and the inverse conj(a) / norm given 1 / norm (the two halves of fq2_target_tree.rs:66-78)
+BLS_HD FpR fp2_norm(const Fp2R& a) { return mul2(a.c0, a.c0, a.c1, a.c1); }
+BLS_HD Fp2R fp2_inv_given(const Fp2R& a, const FpR& norm_inv) { return Fp2R(mul(a.c0, norm_inv), mul(neg(a.c1), norm_inv)); }
+
 // inverse via the norm (fq2_target_tree.rs:66-78); zero maps to zero.
 template <int L, int V>
 BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
   const Fp2R a = fit<1, 2>(a_in);
-  const FpR n = mul2(a.c0, a.c0, a.c1, a.c1);
-  const FpR ni = fp_inv(n);
-  return Fp2R(mul(a.c0, ni), mul(neg(a.c1), ni));
+  return fp2_inv_given(a, fp_inv(fp2_norm(a)));
 }
 
 template <int L, int V>

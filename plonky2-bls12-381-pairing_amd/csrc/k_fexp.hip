@@ -15,6 +15,11 @@ static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bl
 // Final exponentiation, in place allowed (in == out: each lane pair reads its element before writing it).
 // Two waves per SIMD: the cyclotomic-squaring runs need ~250 registers, and with two waves the SIMD issues a MAD
 // every ~4.2 cycles instead of ~5.6 (profiles/r01_v3: 44-46 ms vs 52 ms per 2^18 elements).
+//
+// k_final_exp is the self-contained form (one Fermat inversion per lane, ~9 % of the kernel).  The split form amortises
+// that inversion over the batch:  k_fexp_norm writes the Fp norm under f^-1 for every element,  k_fp_batch_inv
+// (k_misc.hip) inverts them eight per lane with Montgomery's trick,  k_final_exp_given finishes f^-1 from the supplied
+// norm inverse and runs the rest.  Same field values, hence the same output bits.
 __global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
@@ -24,8 +29,36 @@ k_final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int for
   if (flags && lane_part() == 0) flags[i] = 0;
 }
 
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_fexp_norm(const uint64_t* __restrict__ in, uint32_t* __restrict__ raw, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  const Fp12R f = fp12_load(in + 72 * i, form);
+  const FpR nrm = fp12_inv_norm_call(f);                       // identical on both lanes of the pair
+  if (lane_part() == 0) raw_fp_store(raw + i * RAW_FP_STRIDE, nrm);
+}
+
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_final_exp_given(const uint64_t* in, uint64_t* out, uint8_t* flags, const uint32_t* __restrict__ raw, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  const Fp12R f = fp12_load(in + 72 * i, form);
+  const FpR norm_inv = raw_fp_load(raw + i * RAW_FP_STRIDE);
+  const Fp12R f_inv = fp12_inv_given_call(f, norm_inv);
+  fp12_store(out + 72 * i, final_exponentiation_given_inverse(f, f_inv), form);
+  if (flags && lane_part() == 0) flags[i] = 0;
+}
+
 namespace bls_launch {
-void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
-  hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, block)), dim3(block), 0, s, in, out, flags, n, form);
+// `raw_scratch`: n x RAW_FP_STRIDE dwords of device memory for the split form, or nullptr for the self-contained kernel
+void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {
+  const dim3 grid(grid_for(n, block)), blk(block);
+  if (!raw_scratch) {
+    hipLaunchKernelGGL(k_final_exp, grid, blk, 0, s, in, out, flags, n, form);
+    return;
+  }
+  hipLaunchKernelGGL(k_fexp_norm, grid, blk, 0, s, in, raw_scratch, n, form);
+  fp_batch_inv_raw(raw_scratch, n, s);
+  hipLaunchKernelGGL(k_final_exp_given, grid, blk, 0, s, in, out, flags, (const uint32_t*)raw_scratch, n, form);
 }
 }  // namespace bls_launch

@@ -153,13 +153,36 @@ __global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
   fp12_store(out + 72 * i, Fp12R(fp12_one()), form);
 }
 
+// Simultaneous inversion of n internal-form Fp values in place (raw limbs, RAW_FP_STRIDE dwords apart): one lane per
+// chunk of FP_BATCH_INV_CHUNK values (Montgomery's trick in registers), so the batch pays one Fermat inversion per
+// chunk instead of one per value.  Serves the split final exponentiation (k_fexp.hip).
+constexpr int FP_BATCH_INV_CHUNK = 8;
+__global__ void __launch_bounds__(64)
+k_fp_batch_inv(uint32_t* __restrict__ raw, size_t n) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t first = t * FP_BATCH_INV_CHUNK;
+  if (first >= n) return;
+  FpR x[FP_BATCH_INV_CHUNK];
+#pragma unroll
+  for (int j = 0; j < FP_BATCH_INV_CHUNK; ++j)
+    x[j] = (first + j < n) ? raw_fp_load(raw + (first + j) * RAW_FP_STRIDE) : FpR(fp_one());
+  fp_batch_inv(x);
+#pragma unroll
+  for (int j = 0; j < FP_BATCH_INV_CHUNK; ++j)
+    if (first + j < n) raw_fp_store(raw + (first + j) * RAW_FP_STRIDE, x[j]);
+}
+
 namespace bls_launch {
-bool multi(size_t k, bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s) {
+  const size_t chunks = (n + FP_BATCH_INV_CHUNK - 1) / FP_BATCH_INV_CHUNK;
+  hipLaunchKernelGGL(k_fp_batch_inv, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, raw, n);
+}
+bool multi(size_t k, bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {
   switch (k) {
-    case 1: multi_k1(fe, g1, g2, out, flags, n, form, block, s); return true;
-    case 2: multi_k2(fe, g1, g2, out, flags, n, form, block, s); return true;
-    case 3: multi_k3(fe, g1, g2, out, flags, n, form, block, s); return true;
-    case 4: multi_k4(fe, g1, g2, out, flags, n, form, block, s); return true;
+    case 1: multi_k1(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
+    case 2: multi_k2(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
+    case 3: multi_k3(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
+    case 4: multi_k4(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
     default: return false;
   }
 }

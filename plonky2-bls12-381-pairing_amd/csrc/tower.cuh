@@ -127,17 +127,26 @@ BLS_FN_FP6 auto mul_by_1(const Fp6<L, V>& s, const Fp2<L1, V1>& c1) {
   return fit<1, 64>(make_fp6(mul_xi(mul(s.c2, c1)), mul(s.c0, c1), mul(s.c1, c1)));
 }
 
-// inverse   -- fq6_target_tree.rs:59-89 ; zero maps to zero
+// inverse   -- fq6_target_tree.rs:59-89 ; zero maps to zero.  Written as begin / end around the single Fp inversion
+// it bottoms out in (the norm of `t`), so that callers can supply that inverse from a batched inversion.
+struct Fp6InvState { Fp2R c0, c1, c2, t; };
+BLS_HD FpR fp6_inv_begin(const Fp6R& a, Fp6InvState& st) {
+  st.c0 = fit<1, 2>(sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2))));
+  st.c1 = fit<1, 2>(sub(mul_xi(sqr(a.c2)), mul(a.c0, a.c1)));
+  st.c2 = fit<1, 2>(sub(sqr(a.c1), mul(a.c0, a.c2)));
+  auto tmp = add(mul(a.c1, st.c2), mul(a.c2, st.c1));
+  st.t = fit<1, 2>(add(mul_xi(tmp), mul(a.c0, st.c0)));
+  return fp2_norm(st.t);
+}
+BLS_HD Fp6R fp6_inv_end(const Fp6InvState& st, const FpR& norm_inv) {
+  const Fp2R ti = fp2_inv_given(st.t, norm_inv);
+  return Fp6R(mul(st.c0, ti), mul(st.c1, ti), mul(st.c2, ti));
+}
 template <int L, int V>
 BLS_HD_NOINLINE Fp6R inv(const Fp6<L, V>& a_in) {
-  const Fp6R a = fit<1, 2>(a_in);
-  const auto c0 = fit<1, 2>(sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2))));
-  const auto c1 = fit<1, 2>(sub(mul_xi(sqr(a.c2)), mul(a.c0, a.c1)));
-  const auto c2 = fit<1, 2>(sub(sqr(a.c1), mul(a.c0, a.c2)));
-  auto tmp = add(mul(a.c1, c2), mul(a.c2, c1));
-  auto t = add(mul_xi(tmp), mul(a.c0, c0));
-  const Fp2R ti = inv(t);
-  return Fp6R(mul(c0, ti), mul(c1, ti), mul(c2, ti));
+  Fp6InvState st;
+  const FpR n = fp6_inv_begin(fit<1, 2>(a_in), st);
+  return fp6_inv_end(st, fp_inv(n));
 }
 
 BLS_HD Fp6<1, 1> fp6_zero() { return Fp6<1, 1>(fp2_zero(), fp2_zero(), fp2_zero()); }
@@ -202,13 +211,29 @@ BLS_FN_FP12 Fp12R sqr(const Fp12<L, V>& a) {
 template <int L, int V>
 BLS_HD auto conj(const Fp12<L, V>& a) { return make_fp12(a.c0, neg(a.c1)); }    // fq12_target_tree.rs:53-58
 
-// inverse   -- fq12_target_tree.rs:77-90 ; zero maps to zero
+// inverse   -- fq12_target_tree.rs:77-90 ; zero maps to zero.  Same begin / end split as Fp6: `fp12_inv_norm` is the
+// Fp value whose inverse the whole computation needs (N_{Fp2/Fp} . N_{Fp6/Fp2} . N_{Fp12/Fp6} of a).
+BLS_HD FpR fp12_inv_begin(const Fp12R& a, Fp6InvState& st) {
+  const auto t = sub(fit<1, 2>(sqr(a.c0)), fit<1, 2>(mul_v(fit<1, 2>(sqr(a.c1)))));
+  return fp6_inv_begin(fit<1, 2>(t), st);
+}
+BLS_HD Fp12R fp12_inv_end(const Fp12R& a, const Fp6InvState& st, const FpR& norm_inv) {
+  const Fp6R ti = fp6_inv_end(st, norm_inv);
+  return Fp12R(fit<1, 2>(mul(a.c0, ti)), fit<1, 2>(mul(a.c1, neg(ti))));
+}
 template <int L, int V>
 BLS_HD_NOINLINE Fp12R inv(const Fp12<L, V>& a_in) {
   const Fp12R a = fit<1, 2>(a_in);
-  const auto t = sub(fit<1, 2>(sqr(a.c0)), fit<1, 2>(mul_v(fit<1, 2>(sqr(a.c1)))));
-  const Fp6R ti = inv(t);
-  return Fp12R(fit<1, 2>(mul(a.c0, ti)), fit<1, 2>(mul(a.c1, neg(ti))));
+  Fp6InvState st;
+  const FpR n = fp12_inv_begin(a, st);
+  return fp12_inv_end(a, st, fp_inv(n));
+}
+// out-of-line halves for the split final exponentiation (k_fexp.hip)
+BLS_HD_NOINLINE FpR fp12_inv_norm_call(const Fp12R& a) { Fp6InvState st; return fp12_inv_begin(a, st); }
+BLS_HD_NOINLINE Fp12R fp12_inv_given_call(const Fp12R& a, const FpR& norm_inv) {
+  Fp6InvState st;
+  (void)fp12_inv_begin(a, st);
+  return fp12_inv_end(a, st, norm_inv);
 }
 
 // Frobenius   -- fq12_target_tree.rs:92-128
@@ -297,9 +322,10 @@ BLS_HD_NOINLINE Fp12R cyclotomic_exp(const Fp12R& f) {
 }
 
 // easy part + hard part   -- miller_loop.rs:166-178, :128-164 ; `ok` is false when f == 0 (no inverse)
-BLS_HD_NOINLINE Fp12R final_exponentiation(const Fp12R& f) {
+// `f_inv` = f^-1: computed by the caller, either in place (final_exponentiation below) or from a batched inversion
+BLS_HD_NOINLINE Fp12R final_exponentiation_given_inverse(const Fp12R& f, const Fp12R& f_inv) {
   const Fp12R t0f = fit<1, 2>(conj(f));                   // frobenius^6 == conjugation (:168-174)
-  Fp12R t1 = inv(f);                                      // :175
+  Fp12R t1 = f_inv;                                       // :175
   Fp12R t2 = mul_call(t0f, t1);                                // :133
   t1 = t2;
   t2 = mul_call(frobenius_call(frobenius_call(t2)), t1);                 // :135-136
@@ -325,6 +351,7 @@ BLS_HD_NOINLINE Fp12R final_exponentiation(const Fp12R& f) {
   t3 = mul_call(t3, t6);
   return mul_call(t3, t4);
 }
+BLS_HD_NOINLINE Fp12R final_exponentiation(const Fp12R& f) { return final_exponentiation_given_inverse(f, inv(f)); }
 
 template <int L, int V>
 BLS_HD bool is_zero(const Fp6<L, V>& a) { return is_zero(a.c0) & is_zero(a.c1) & is_zero(a.c2); }

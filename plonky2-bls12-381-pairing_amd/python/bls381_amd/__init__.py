@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hip.so"))
 
 IO_ARK_MONT, IO_CANONICAL = 0, 1
-OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE = 0, 1, 2
+OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE, OPT_FEXP_BATCHED_INVERSION = 0, 1, 2, 3
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
 FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV, FP_LEGENDRE, FP_IS_SQUARE, FP_SGN0 = range(12)

@@ -103,8 +103,32 @@ int hostsim_fp2_op(int op, int form, const uint64_t* a, const uint64_t* b, uint6
 }
 
 enum { OP12_MUL = 0, OP12_SQR = 1, OP12_INV = 2, OP12_FROBENIUS = 3, OP12_CYC_SQR = 4, OP12_CONJ = 5,
-       OP12_CYC_EXP = 6, OP12_FINAL_EXP = 7 };
+       OP12_CYC_EXP = 6, OP12_FINAL_EXP = 7, OP12_FINAL_EXP_SPLIT = 8 };
+
+// The split final exponentiation exactly as the three kernels run it (k_fexp_norm, k_fp_batch_inv in chunks of eight
+// with the tail padded by ones, k_final_exp_given), raw limbs parked 16 dwords apart in between.
+static int final_exp_split(int form, const uint64_t* a, uint64_t* out, size_t n) {
+  constexpr int CHUNK = 8;
+  uint32_t* raw = (uint32_t*)calloc(n ? n : 1, RAW_FP_STRIDE * sizeof(uint32_t));
+  if (!raw) return 2;
+  for (size_t i = 0; i < n; ++i) raw_fp_store(raw + i * RAW_FP_STRIDE, fp12_inv_norm_call(fp12_load(a + 72 * i, form)));
+  for (size_t first = 0; first < n; first += CHUNK) {
+    FpR x[CHUNK];
+    for (int j = 0; j < CHUNK; ++j) x[j] = (first + j < n) ? raw_fp_load(raw + (first + j) * RAW_FP_STRIDE) : FpR(fp_one());
+    fp_batch_inv(x);
+    for (int j = 0; j < CHUNK; ++j) if (first + j < n) raw_fp_store(raw + (first + j) * RAW_FP_STRIDE, x[j]);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const Fp12R f = fp12_load(a + 72 * i, form);
+    const Fp12R f_inv = fp12_inv_given_call(f, raw_fp_load(raw + i * RAW_FP_STRIDE));
+    fp12_store(out + 72 * i, final_exponentiation_given_inverse(f, f_inv), form);
+  }
+  free(raw);
+  return 0;
+}
+
 int hostsim_fp12_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (op == OP12_FINAL_EXP_SPLIT) return final_exp_split(form, a, out, n);
   for (size_t i = 0; i < n; ++i) {
     Fp12R x = fp12_load(a + 72 * i, form);
     Fp12R y = b ? fp12_load(b + 72 * i, form) : x;

@@ -58,6 +58,39 @@ def test_tower_ops_golden(engine):
     assert dec_fp12s(engine.fp12_op(B.FP12_CYCLOTOMIC_EXP, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
 
 
+def test_final_exp_batched_inversion_matches_self_contained(engine):
+    """BLS381_OPT_FEXP_BATCHED_INVERSION: the split final exponentiation (norm kernel, simultaneous inversion eight per
+    lane, finishing kernel) and the self-contained kernel give the oracle's bits, for ragged batch sizes (chunk tails,
+    context scratch growing between calls) and with zero elements inside a chunk (zero stays zero, neighbours intact)."""
+    rng = random.Random(401)
+    vals = [rand_fp12(rng) for _ in range(21)]
+    zero = O.fp12_unflatten([0] * 12)
+    vals[3] = zero; vals[16] = zero
+    exp = [O.final_exponentiation(v) or zero for v in vals]
+    X = enc_fp12s(vals)
+    assert engine.get_option(B.OPT_FEXP_BATCHED_INVERSION) == 1            # default
+    try:
+        for batched in (1, 0):
+            engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, batched)
+            for n in (1, 7, 8, 9, 21):
+                assert dec_fp12s(engine.final_exponentiation(X[: 72 * n])) == exp[:n], (batched, n)
+    finally:
+        engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, 1)
+
+
+def test_pairing_same_bits_with_and_without_batched_inversion(engine, coracle):
+    n = 300                                                               # not a multiple of the chunk or the wave
+    g1, g2 = synthetic_batch(n, jacobian=False, pool=16)
+    exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
+    try:
+        for batched in (1, 0):
+            engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, batched)
+            out, fl = engine.multi_pairing(g1, g2, 1)
+            assert np.array_equal(out, exp) and np.array_equal(fl, efl), batched
+    finally:
+        engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, 1)
+
+
 def test_tower_identities_kat5(engine):
     """x^2 == x*x and (a+b) c^2 == c^2 a + c^2 b on device (the reference's test_fq12_arithmetic shape)."""
     rng = random.Random(55)

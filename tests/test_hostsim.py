@@ -62,6 +62,21 @@ def test_tower_golden(hostsim):
     assert dec_fp12s(hostsim.fp12_op(6, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
 
 
+def test_final_exp_split_with_batched_inversion(hostsim):
+    """The three-kernel form of the final exponentiation (norms -> simultaneous inversion in chunks of eight -> finish)
+    gives the oracle's bits for every element, whatever the chunk alignment; zero elements stay zero and do not disturb
+    the others of their chunk."""
+    rng = random.Random(77)
+    vals = [rand_fp12(rng) for _ in range(11)]          # 8 + a ragged tail of 3
+    vals[2] = O.fp12_unflatten([0] * 12)                # zero: no inverse (the reference would panic); stays zero
+    X = enc_fp12s(vals)
+    exp = [O.final_exponentiation(v) or vals[2] for v in vals]
+    assert dec_fp12s(hostsim.fp12_op(8, X)) == exp
+    assert dec_fp12s(hostsim.fp12_op(7, X)) == exp
+    for n in (1, 7, 8, 9):
+        assert dec_fp12s(hostsim.fp12_op(8, X[:72 * n])) == exp[:n], n
+
+
 def test_mode_a_golden_both_variants(hostsim):
     cases = load_golden("mode_a.json")["cases"]
     g1 = enc_fps([v for c in cases for v in hx(c["g1_jac"])])

@@ -11,7 +11,8 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-KERNELS = ("k_multi_miller", "k_final_exp")     # one bench step = one launch of each
+# one bench step = one launch of each ("k_final_exp" also matches k_final_exp_given; only one of the two runs)
+KERNELS = ("k_multi_miller", "k_fexp_norm", "k_fp_batch_inv", "k_final_exp")
 
 
 def counters(path):
