@@ -56,6 +56,8 @@ def main():
                     help="1 (library default): batch-wide simultaneous inversion under the final exponentiation; 0: self-contained kernel")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
                     "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
+    ap.add_argument("--exchange", action="store_true", help="after the timed region, run the one-rank-owns-the-batch flow once: "
+                    "RCCL scatter of the inputs from rank 0, local launch, gather of the results (config.exchange); untimed by `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -150,6 +152,38 @@ def main():
             assert full.numel() == n_units * world * 72
         del full
 
+    exchange = None
+    if args.exchange and distributed and args.workload == "pairing":
+        # SURVEY 8e flow for a caller whose batch lives on rank 0: scatter inputs, launch, gather results (bls381_amd.sharding).
+        # Every range of the full batch repeats rank 0's shard, so rank 0 can check the gathered result against its own.
+        from bls381_amd.sharding import scatter_batch, gather_results
+        host = args.backend != "nccl"                     # gloo rehearsal: point-to-point needs CPU tensors
+        xdev = torch.device("cpu") if host else dev
+        n_total = n_units * world
+        full_in = [d1.repeat(world).to(xdev), d2.repeat(world).to(xdev)] if rank == 0 else None
+        torch.cuda.synchronize(); dist.barrier()
+        x0 = time.perf_counter()
+        a, b = scatter_batch(full_in, [12, 24], n_total, src=0, device=xdev)
+        torch.cuda.synchronize(); dist.barrier()
+        x1 = time.perf_counter()
+        a, b = a.to(dev), b.to(dev)
+        xo = torch.empty(n_units * 72, dtype=torch.int64, device=dev); xf = torch.empty(n_units, dtype=torch.uint8, device=dev)
+        eng.multi_pairing_dev(a.data_ptr(), b.data_ptr(), 1, xo.data_ptr(), xf.data_ptr(), n_units)
+        torch.cuda.synchronize(); dist.barrier()
+        x2 = time.perf_counter()
+        res = gather_results([xo.to(xdev), xf.to(xdev)], [72, 1], n_total, dst=0)
+        torch.cuda.synchronize(); dist.barrier()
+        x3 = time.perf_counter()
+        if rank == 0:
+            same = all(torch.equal(res[0][r * n_units * 72:(r + 1) * n_units * 72].to(dev), dout) for r in range(world))
+            if not same:
+                raise SystemExit("bench: scattered/gathered results differ from the resident-shard results")
+            in_b, out_b = n_total * 288 * (world - 1) / world, n_total * 577 * (world - 1) / world
+            exchange = {"scatter_ms": (x1 - x0) * 1e3, "compute_ms": (x2 - x1) * 1e3, "gather_ms": (x3 - x2) * 1e3,
+                        "scatter_GBps": in_b / (x1 - x0) / 1e9, "gather_GBps": out_b / (x3 - x2) / 1e9,
+                        "end_to_end_pairings_per_s": n_total / (x3 - x0), "staged_through_host": host}
+        del full_in, res
+
     # spot parity inside the bench: the first 64 results of this rank against the oracle (checker only)
     ok = None
     if rank == 0 and args.workload == "pairing":
@@ -187,7 +221,7 @@ def main():
             "config": {"workload": "batch 2^%d full pairings (Miller loop + Fp12 final exponentiation), 1xMI355X per rank"
                                    % args.batch_log2 if args.workload == "pairing" else args.workload,
                        "batch_per_gpu": n_units, "pairs_per_unit": k, "io": "arkworks Montgomery 6xu64 AoS, resident in HBM",
-                       "parity_spot_check": ok, "gather_ms": gather_ms},
+                       "parity_spot_check": ok, "gather_ms": gather_ms, "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",

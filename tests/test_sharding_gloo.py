@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from blsutil import ROOT, synthetic_batch, COracle
 
-from bls381_amd.sharding import shard_range, shard_inputs, gather_outputs
+from bls381_amd.sharding import shard_range, shard_inputs, gather_outputs, scatter_batch, gather_results, sharded_pairing
 
 
 def test_shard_range_partitions():
@@ -60,3 +60,50 @@ def test_two_rank_gloo_matches_single_process(n, k):
     g1, g2 = synthetic_batch(n, seed=31337, jacobian=False, k=k, pool=8)
     exp, _ = COracle().multi(g1, g2, k, final_exp=True)
     assert np.array_equal(got, exp)
+
+
+def _exchange_worker(rank, world, port, n, k, root, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g1 = g2 = None
+        if rank == root:                                   # the batch exists on the root only
+            a, b = synthetic_batch(n, seed=4711, jacobian=False, k=k, pool=8)
+            g1 = torch.from_numpy(a.view(np.int64)); g2 = torch.from_numpy(b.view(np.int64))
+
+        def run_local(l1, l2, n_local):                    # the C oracle stands in for the GPU launch (no GPU here)
+            assert l1.numel() == n_local * 12 * k and l2.numel() == n_local * 24 * k
+            if n_local == 0:
+                return torch.empty(0, dtype=torch.int64), torch.empty(0, dtype=torch.uint8)
+            out, fl = COracle().multi(np.ascontiguousarray(l1.numpy().view(np.uint64)), np.ascontiguousarray(l2.numpy().view(np.uint64)),
+                                      k, final_exp=True)
+            return torch.from_numpy(out.view(np.int64)), torch.from_numpy(fl)
+
+        out, fl = sharded_pairing(run_local, g1, g2, k, n, root=root)
+        dist.barrier()
+        if rank == root:
+            q.put((out.numpy().view(np.uint64).copy(), fl.numpy().copy()))
+        else:
+            assert out is None and fl is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k,root,world", [(13, 1, 0, 2), (5, 3, 1, 2), (2, 1, 0, 3)])
+def test_scatter_compute_gather_from_one_rank(n, k, root, world):
+    """scatter_batch -> local launch -> gather_results with the batch living on one rank: ragged ranges (13 over 2), a
+    non-zero root, and a world larger than the batch (an empty range on one rank)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n, k, root, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, gfl = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = synthetic_batch(n, seed=4711, jacobian=False, k=k, pool=8)
+    exp, efl = COracle().multi(a, b, k, final_exp=True)
+    assert np.array_equal(got, exp) and np.array_equal(gfl, efl)
