@@ -54,7 +54,9 @@ enum {
 /* per-element flag bits */
 enum {
   BLS381_FLAG_DEN_ZERO = 1, /* Mode A: f_den == 0, the reference panics at opt.rs:102; output zeroed */
-  BLS381_FLAG_INFINITY = 2  /* an input point at infinity: pair skipped (result 1 if all pairs skipped) */
+  BLS381_FLAG_INFINITY = 2, /* an input point at infinity: pair skipped (result 1 if all pairs skipped); point ops: the result
+                               (predicates: the first operand) is the point at infinity */
+  BLS381_FLAG_TRUE = 32     /* point predicates (BLS381_POINT_EQ, BLS381_POINT_IS_ON_CURVE): the predicate holds */
 };
 
 enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
@@ -81,6 +83,17 @@ enum { BLS381_FP6_ADD = 0, BLS381_FP6_SUB = 1, BLS381_FP6_MUL = 2, BLS381_FP6_SQ
 /* Fp12 ops */
 enum { BLS381_FP12_MUL = 0, BLS381_FP12_SQR = 1, BLS381_FP12_INV = 2, BLS381_FP12_FROBENIUS = 3,
        BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6 };
+
+/* Point ops on Jacobian points (arkworks `Projective`: x = X/Z^2, y = Y/Z^3; Z = 0 is the point at infinity) */
+enum { BLS381_POINT_ADD = 0        /* ark-ec 0.4.2 `Projective += &Projective` (add-2007-bl with the equal -> double and
+                                      infinity fallbacks) [third party]: the `R + R`, `R + Q` of src/miller_loop_native_optimized.rs:93,98 */,
+       BLS381_POINT_DOUBLE = 1     /* `double_in_place` (dbl-2009-l, a = 0) */,
+       BLS381_POINT_NORMALIZE = 2  /* the Z = 1 representative (`.into()` to affine and back, opt.rs:93,98;
+                                      `From<G2AffineTarget> for G2ProjectiveTarget`, src/fields_as_trees/g2_curve.rs:29-50);
+                                      infinity -> (1, 1, 0) */,
+       BLS381_POINT_EQ = 3         /* point equality, flags bit BLS381_FLAG_TRUE (`is_point_equal_to`, g2_curve.rs:129-149,
+                                      g1_curve.rs:79-110: both at infinity, or neither and equal coordinates) */,
+       BLS381_POINT_IS_ON_CURVE = 4 /* Y^2 == X^3 + b Z^6, b = 4 (G1) / 4(1+u) (G2); flags bit BLS381_FLAG_TRUE */ };
 
 /* lifecycle ------------------------------------------------------------------------------------------ */
 int bls381_create(bls381_ctx** out, int device_id);
@@ -161,6 +174,13 @@ int bls381_fp_pow_batch(bls381_ctx* ctx, const uint64_t* a, const uint64_t* exp,
  * ell(f) = f.mul_by_014(c, b * P.x, a * P.y)).  An infinite input is replaced by the generator and flagged
  * BLS381_FLAG_INFINITY, as the reference does (:58-60). */
 int bls381_g2_prepare_batch(bls381_ctx* ctx, const uint64_t* g2_aff, uint64_t* coeffs, uint8_t* flags, size_t n);
+
+/* G1 / G2 point ops (src/curves/*, src/fields_as_trees/g{1,2}_curve.rs; arkworks group law at opt.rs:93,98).
+ * a, b, out: n x 3 x 6 u64 (G1) / n x 3 x 2 x 6 (G2) Jacobian points; b is read by ADD and EQ only.  ADD / DOUBLE / NORMALIZE
+ * write `out` (flags optional: BLS381_FLAG_INFINITY when the result is the point at infinity); EQ / IS_ON_CURVE answer in
+ * `flags` (required) and leave `out` untouched (may be NULL). */
+int bls381_g1_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n);
+int bls381_g2_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n);
 
 /* Witness-generator backend: batch forms of the `SimpleGenerator::run_once` hooks through which
  * plonky2 invokes native arithmetic while filling a witness.  Elements are CANONICAL integers as 12 x u32

@@ -510,6 +510,37 @@ def jac_to_affine(F, pt):
     return (F.mul(X, zi2), F.mul(Y, F.mul(zi2, zi)))
 
 
+def jac_eq(F, p1, p2):
+    """arkworks `Projective == Projective` [3P]: both at infinity, or neither and X1 Z2^2 == X2 Z1^2, Y1 Z2^3 == Y2 Z1^3.
+    On normalised points this is the reference's `is_point_equal_to` (src/fields_as_trees/g2_curve.rs:129-149,
+    g1_curve.rs:79-110)."""
+    z1, z2 = F.is_zero(p1[2]), F.is_zero(p2[2])
+    if z1 or z2:
+        return z1 and z2
+    a, b = F.sqr(p1[2]), F.sqr(p2[2])
+    return F.eq(F.mul(p1[0], b), F.mul(p2[0], a)) and F.eq(F.mul(p1[1], F.mul(b, p2[2])), F.mul(p2[1], F.mul(a, p1[2])))
+
+
+def jac_on_curve(F, pt):
+    """Y^2 == X^3 + b Z^6 (b = 4 on G1, 4(1+u) on the twist); infinity counts as on the curve."""
+    X, Y, Z = pt
+    if F.is_zero(Z):
+        return True
+    z2 = F.sqr(Z)
+    z6 = F.mul(F.sqr(z2), z2)
+    b = (B_G1 * z6) % P if F is _F1 else fp2_mul(B_G2, z6)
+    return F.eq(F.sqr(Y), F.add(F.mul(F.sqr(X), X), b))
+
+
+def jac_normalize(F, pt):
+    """The Z = 1 representative (`.into()` to affine and back, opt.rs:93,98; `From<G2AffineTarget>` g2_curve.rs:29-50);
+    infinity -> arkworks' `Projective::zero()` = (1, 1, 0)."""
+    a = jac_to_affine(F, pt)
+    if a is None:
+        return (F.one, F.one, F.zero)
+    return (a[0], a[1], F.one)
+
+
 def jac_from_affine(F, a):
     return (a[0], a[1], F.one)
 

@@ -398,6 +398,37 @@ int bls381_g2_prepare_batch(bls381_ctx* c, const uint64_t* g2_aff, uint64_t* coe
                       });
 }
 
+// ---- point surface (G1 / G2 Jacobian points)
+static int point_op(bls381_ctx* c, int group, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n) {
+  const bool binary = op == BLS381_POINT_ADD || op == BLS381_POINT_EQ;
+  const bool predicate = op == BLS381_POINT_EQ || op == BLS381_POINT_IS_ON_CURVE;
+  if (!c || op < BLS381_POINT_ADD || op > BLS381_POINT_IS_ON_CURVE) return BLS381_E_INVALID;
+  if (n && (!a || (binary && !b) || (predicate ? !flags : !out))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  const size_t bytes = n * (group == 1 ? 144 : 288);
+  if (predicate) out = nullptr;                              // predicates answer in flags only
+  if (!binary) b = nullptr;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DevBuf da, db, dout, dfl;
+  HIP_TRY(c, hipMalloc(&da.p, bytes));
+  HIP_TRY(c, hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, c->stream));
+  if (b) { HIP_TRY(c, hipMalloc(&db.p, bytes)); HIP_TRY(c, hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, c->stream)); }
+  if (out) HIP_TRY(c, hipMalloc(&dout.p, bytes));
+  if (flags) HIP_TRY(c, hipMalloc(&dfl.p, n));
+  bls_launch::point_op(group, op, (const uint64_t*)da.p, (const uint64_t*)db.p, (uint64_t*)dout.p, (uint8_t*)dfl.p, n, c->io_form, c->block, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  if (out) HIP_TRY(c, hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  if (flags) HIP_TRY(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BLS381_OK;
+}
+int bls381_g1_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n) {
+  return point_op(c, 1, op, a, b, out, flags, n);
+}
+int bls381_g2_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n) {
+  return point_op(c, 2, op, a, b, out, flags, n);
+}
+
 // ---- witness-generator backend (canonical 12 x u32 digits == 6 x u64 per Fp)
 static int witness_inverse(bls381_ctx* c, int op, size_t fp_per_elem, const uint32_t* x, uint32_t* inv, uint8_t* flags, size_t n) {
   if (!c || (n && (!x || !inv))) return BLS381_E_INVALID;

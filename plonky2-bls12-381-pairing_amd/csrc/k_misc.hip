@@ -153,6 +153,22 @@ __global__ void k_fill_one(uint64_t* __restrict__ out, size_t n, int form) {
   fp12_store(out + 72 * i, Fp12R(fp12_one()), form);
 }
 
+// Point surface: one Jacobian point (pair) per lane pair; W = u64 words per point (18 on G1, 36 on G2).  On G1 both
+// lanes of a pair compute the same Fp values (like k_fp_op).
+template <class F, int W>
+__global__ void __launch_bounds__(BLS_MAX_BLOCK)
+k_point_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out,
+           uint8_t* __restrict__ flags, size_t n, int form) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  if (i >= n) return;
+  Jac<F> x, y, r;
+  jac_load(x, a + (size_t)W * i, form);
+  if (b) jac_load(y, b + (size_t)W * i, form); else y = x;
+  const uint8_t fl = point_op(op, x, y, r);
+  if (out) jac_store(out + (size_t)W * i, r, form);
+  if (flags && lane_part() == 0) flags[i] = fl;
+}
+
 // Simultaneous inversion of n internal-form Fp values in place (raw limbs, RAW_FP_STRIDE dwords apart): one lane per
 // chunk of FP_BATCH_INV_CHUNK values (Montgomery's trick in registers), so the batch pays one Fermat inversion per
 // chunk instead of one per value.  Serves the split final exponentiation (k_fexp.hip).
@@ -173,6 +189,10 @@ k_fp_batch_inv(uint32_t* __restrict__ raw, size_t n) {
 }
 
 namespace bls_launch {
+void point_op(int group, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  if (group == 1) hipLaunchKernelGGL((k_point_op<FpR, 18>), dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, flags, n, form);
+  else hipLaunchKernelGGL((k_point_op<Fp2R, 36>), dim3(grid_for(n, block)), dim3(block), 0, s, op, a, b, out, flags, n, form);
+}
 void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s) {
   const size_t chunks = (n + FP_BATCH_INV_CHUNK - 1) / FP_BATCH_INV_CHUNK;
   hipLaunchKernelGGL(k_fp_batch_inv, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, raw, n);

@@ -19,6 +19,8 @@ void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t 
 void fp6_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uint64_t* out, size_t n, int form, int block, hipStream_t s);
+// group 1 = G1 (n x 3 x 6 u64), 2 = G2 (n x 3 x 2 x 6)
+void point_op(int group, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void fill_one(uint64_t* out, size_t n, int form, hipStream_t s);
 // Miller kernel with LDS-staged fixed-G2 coefficients, then the final exponentiation in place
 bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);

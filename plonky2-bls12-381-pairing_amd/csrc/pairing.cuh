@@ -23,50 +23,141 @@ namespace bls {
 
 enum : uint8_t { FLAG_DEN_ZERO = 1, FLAG_INFINITY = 2 };
 
-struct G2Jac { Fp2R x, y, z; };
-struct G1Jac { FpR x, y, z; };
+template <class F> struct Jac { F x, y, z; };     // arkworks `Projective`: Jacobian (X, Y, Z), x = X/Z^2, y = Y/Z^3
+using G2Jac = Jac<Fp2R>;
+using G1Jac = Jac<FpR>;
 struct G2Aff { Fp2R x, y; };
 struct G1Aff { FpR x, y; };
 
 // Exact zero / equality tests on field values (the reference compares canonical arkworks elements).
 template <int La, int Va, int Lb, int Vb>
 BLS_HD bool eq(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return is_zero(sub(a, b)); }
+template <int La, int Va, int Lb, int Vb>
+BLS_HD bool eq(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) { return fp_eq(a, b); }
+template <int L, int V>
+BLS_HD FpR inv(const Fp<L, V>& a) { return fp_inv(a); }
 
-// ------------------------------------------------------------------------------------- Jacobian G2
+// field-generic constants for the curve routines below (F = FpR for G1, Fp2R for G2)
+BLS_HD void set_one(FpR& r) { r = FpR(fp_one()); }
+BLS_HD void set_one(Fp2R& r) { r = Fp2R(fp2_one()); }
+BLS_HD void set_zero(FpR& r) { r = FpR(fp_zero()); }
+BLS_HD void set_zero(Fp2R& r) { r = Fp2R(fp2_zero()); }
+// curve constant times v: b = 4 on G1 (y^2 = x^3 + 4), b = 4 (1 + u) on the twist
+template <int L, int V> BLS_HD auto mul_curve_b(const Fp<L, V>& v) { return dbl(dbl(v)); }
+template <int L, int V> BLS_HD auto mul_curve_b(const Fp2<L, V>& v) { return dbl(dbl(mul_xi(v))); }
+
+// products with automatic operand conditioning for either field (the Fp2 backends already condition; plain Fp
+// products static_assert instead, so the field-generic curve routines go through these)
+template <int La, int Va, int Lb, int Vb>
+BLS_HD FpR fmul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+  if constexpr (La * Lb <= MONT_LL_MAX && Va * Vb <= MONT_VV_MAX) return mul(a, b);
+  else if constexpr (Va * Vb > MONT_VV_MAX) { if constexpr (Va >= Vb) return fmul(fit<1, 2>(a), b); else return fmul(a, fit<1, 2>(b)); }
+  else { if constexpr (La >= Lb) return fmul(fit<1, Va>(a), b); else return fmul(a, fit<1, Vb>(b)); }
+}
+template <int L, int V>
+BLS_HD FpR fsqr(const Fp<L, V>& a) {
+  if constexpr (L * L <= MONT_LL_MAX && V * V <= MONT_VV_MAX) return sqr(a);
+  else if constexpr (V * V > MONT_VV_MAX) return fsqr(fit<1, 2>(a));
+  else return fsqr(fit<1, V>(a));
+}
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2R fmul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return mul(a, b); }
+template <int L, int V>
+BLS_HD Fp2R fsqr(const Fp2<L, V>& a) { return sqr(a); }
+
+// ---------------------------------------------------------------------- Jacobian G1 / G2 (field-generic)
+BLS_HD_NOINLINE G2Jac jac_double_call(const G2Jac& p);
+BLS_HD_NOINLINE G1Jac jac_double_call(const G1Jac& p);
+
 // ark-ec 0.4.2 `Projective::double_in_place`, a = 0 (EFD dbl-2009-l) [third party; SURVEY App. A.3]
-BLS_HD_NOINLINE G2Jac g2_jac_double(const G2Jac& p) {
+template <class F>
+BLS_HD Jac<F> jac_double(const Jac<F>& p) {
   if (is_zero(p.z)) return p;
-  const Fp2R A = sqr(p.x), B = sqr(p.y), C = sqr(B);
-  const auto D = dbl(sub(sub(sqr(add(p.x, B)), A), C));
+  const F A = fsqr(p.x), B = fsqr(p.y), C = fsqr(B);
+  const auto D = dbl(sub(sub(fsqr(add(p.x, B)), A), C));
   const auto E = add(dbl(A), A);
-  const Fp2R F = sqr(E);
-  G2Jac r;
-  r.z = fit<1, 2>(dbl(mul(p.y, p.z)));
-  const auto X3 = fit<1, 2>(sub(sub(F, D), D));
+  const F Fv = fsqr(E);
+  Jac<F> r;
+  r.z = fit<1, 2>(dbl(fmul(p.y, p.z)));
+  const auto X3 = fit<1, 2>(sub(sub(Fv, D), D));
   r.x = X3;
-  r.y = fit<1, 2>(sub(mul(E, sub(D, X3)), dbl(dbl(dbl(C)))));
+  r.y = fit<1, 2>(sub(fmul(E, sub(D, X3)), dbl(dbl(dbl(C)))));
   return r;
 }
 
 // ark-ec 0.4.2 `impl AddAssign<&Self> for Projective` (EFD add-2007-bl) [third party; SURVEY App. A.3]
-BLS_HD_NOINLINE G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) {
+template <class F>
+BLS_HD Jac<F> jac_add(const Jac<F>& p1, const Jac<F>& p2) {
   if (is_zero(p1.z)) return p2;
   if (is_zero(p2.z)) return p1;
-  const Fp2R Z1Z1 = sqr(p1.z), Z2Z2 = sqr(p2.z);
-  const Fp2R U1 = mul(p1.x, Z2Z2), U2 = mul(p2.x, Z1Z1);
-  const Fp2R S1 = mul(mul(p1.y, p2.z), Z2Z2), S2 = mul(mul(p2.y, p1.z), Z1Z1);
-  if (eq(U1, U2) && eq(S1, S2)) return g2_jac_double(p1);
+  const F Z1Z1 = fsqr(p1.z), Z2Z2 = fsqr(p2.z);
+  const F U1 = fmul(p1.x, Z2Z2), U2 = fmul(p2.x, Z1Z1);
+  const F S1 = fmul(fmul(p1.y, p2.z), Z2Z2), S2 = fmul(fmul(p2.y, p1.z), Z1Z1);
+  if (eq(U1, U2) && eq(S1, S2)) return jac_double_call(p1);
   const auto H = sub(U2, U1);
-  const Fp2R I = sqr(dbl(H));
-  const Fp2R J = mul(H, I);
+  const F I = fsqr(dbl(H));
+  const F J = fmul(H, I);
   const auto r = dbl(sub(S2, S1));
-  const Fp2R V = mul(U1, I);
-  G2Jac o;
-  const auto X3 = fit<1, 2>(sub(sub(sqr(r), J), dbl(V)));
+  const F V = fmul(U1, I);
+  Jac<F> o;
+  const auto X3 = fit<1, 2>(sub(sub(fsqr(r), J), dbl(V)));
   o.x = X3;
-  o.y = fit<1, 2>(sub(mul(r, sub(V, X3)), dbl(mul(S1, J))));
-  o.z = fit<1, 2>(mul(sub(sub(sqr(add(p1.z, p2.z)), Z1Z1), Z2Z2), H));
+  o.y = fit<1, 2>(sub(fmul(r, sub(V, X3)), dbl(fmul(S1, J))));
+  o.z = fit<1, 2>(fmul(sub(sub(fsqr(add(p1.z, p2.z)), Z1Z1), Z2Z2), H));
   return o;
+}
+BLS_HD_NOINLINE G2Jac jac_double_call(const G2Jac& p) { return jac_double(p); }
+BLS_HD_NOINLINE G1Jac jac_double_call(const G1Jac& p) { return jac_double(p); }
+BLS_HD G2Jac g2_jac_double(const G2Jac& p) { return jac_double_call(p); }
+BLS_HD_NOINLINE G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) { return jac_add(p1, p2); }
+
+// Point helpers around the pairing (the reference's curve types: src/fields_as_trees/g2_curve.rs:29-166,
+// g1_curve.rs:22-110; arkworks `Projective` equality / normalisation [third party]).
+enum : int { POINT_ADD = 0, POINT_DOUBLE = 1, POINT_NORMALIZE = 2, POINT_EQ = 3, POINT_ON_CURVE = 4 };
+enum : uint8_t { FLAG_TRUE = 32 };
+
+// `Projective == Projective`: both at infinity, or neither and X1 Z2^2 == X2 Z1^2, Y1 Z2^3 == Y2 Z1^3
+template <class F>
+BLS_HD bool jac_eq(const Jac<F>& a, const Jac<F>& b) {
+  const bool za = is_zero(a.z), zb = is_zero(b.z);
+  if (za || zb) return za && zb;
+  const F z1z1 = fsqr(a.z), z2z2 = fsqr(b.z);
+  return eq(fmul(a.x, z2z2), fmul(b.x, z1z1)) && eq(fmul(a.y, fmul(z2z2, b.z)), fmul(b.y, fmul(z1z1, a.z)));
+}
+// Y^2 == X^3 + b Z^6 (infinity counts as on the curve)
+template <class F>
+BLS_HD bool jac_on_curve(const Jac<F>& a) {
+  if (is_zero(a.z)) return true;
+  const F z2 = fsqr(a.z);
+  const F z6 = fmul(fsqr(z2), z2);
+  return eq(fsqr(a.y), add(fmul(fsqr(a.x), a.x), mul_curve_b(z6)));
+}
+// the representative with Z = 1 (`Affine::from(Projective)` followed by `Projective::from`); infinity -> (1, 1, 0),
+// arkworks' `Projective::zero()`
+template <class F>
+BLS_HD Jac<F> jac_normalize(const Jac<F>& a) {
+  Jac<F> r;
+  if (is_zero(a.z)) { set_one(r.x); set_one(r.y); set_zero(r.z); return r; }
+  const F zi = inv(a.z);
+  const F zi2 = fsqr(zi);
+  r.x = fmul(a.x, zi2);
+  r.y = fmul(a.y, fmul(zi2, zi));
+  set_one(r.z);
+  return r;
+}
+// one element of bls381_g1_op_batch / bls381_g2_op_batch; returns the flag byte
+template <class F>
+BLS_HD uint8_t point_op(int op, const Jac<F>& a, const Jac<F>& b, Jac<F>& r) {
+  bool pred = false;
+  switch (op) {
+    case POINT_ADD: r = jac_add(a, b); break;
+    case POINT_DOUBLE: r = jac_double_call(a); break;
+    case POINT_NORMALIZE: r = jac_normalize(a); break;
+    case POINT_EQ: r = a; pred = jac_eq(a, b); break;
+    case POINT_ON_CURVE: r = a; pred = jac_on_curve(a); break;
+    default: r = a; break;
+  }
+  return (uint8_t)((is_zero(r.z) ? FLAG_INFINITY : 0) | (pred ? FLAG_TRUE : 0));
 }
 
 // ------------------------------------------------------------------------------------------ Mode A
@@ -277,6 +368,10 @@ BLS_HD G1Jac g1_jac_load(const uint64_t* w, int form) {
 BLS_HD G2Jac g2_jac_load(const uint64_t* w, int form) {
   G2Jac q; q.x = fp2_load(w, form); q.y = fp2_load(w + 12, form); q.z = fp2_load(w + 24, form); return q;
 }
+BLS_HD void jac_load(G1Jac& p, const uint64_t* w, int form) { p = g1_jac_load(w, form); }
+BLS_HD void jac_load(G2Jac& q, const uint64_t* w, int form) { q = g2_jac_load(w, form); }
+BLS_HD void jac_store(uint64_t* w, const G1Jac& p, int form) { fp_store(w, p.x, form); fp_store(w + 6, p.y, form); fp_store(w + 12, p.z, form); }
+BLS_HD void jac_store(uint64_t* w, const G2Jac& q, int form) { fp2_store(w, q.x, form); fp2_store(w + 12, q.y, form); fp2_store(w + 24, q.z, form); }
 // affine points; the all-zero encoding (x = y = 0, not on either curve) denotes the point at infinity
 BLS_HD G1Aff g1_aff_load(const uint64_t* w, int form, bool& inf) {
   uint64_t o = 0;

@@ -20,6 +20,8 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hi
 IO_ARK_MONT, IO_CANONICAL = 0, 1
 OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE, OPT_FEXP_BATCHED_INVERSION = 0, 1, 2, 3
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
+FLAG_TRUE = 32
+POINT_ADD, POINT_DOUBLE, POINT_NORMALIZE, POINT_EQ, POINT_IS_ON_CURVE = range(5)
 FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
 FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV, FP_LEGENDRE, FP_IS_SQUARE, FP_SGN0 = range(12)
 FP2_ADD, FP2_SUB, FP2_MUL, FP2_SQR, FP2_INV, FP2_NEG, FP2_CONJ, FP2_MUL_BY_NONRESIDUE = range(8)
@@ -42,6 +44,7 @@ SYMBOLS = [
     "bls381_fq12_ark_to_myfq12", "bls381_fq12_myfq12_to_ark",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
+    "bls381_g1_op_batch", "bls381_g2_op_batch",
 ]
 
 
@@ -82,6 +85,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_debug_line_ref_opt_batch.argtypes = [vp, u64p, u64p, u64p, u64p, sz]
     lib.bls381_g2_prepare_batch.argtypes = [vp, u64p, u64p, u8p, sz]
     lib.bls381_fp_pow_batch.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
+    lib.bls381_g1_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, u8p, sz]
+    lib.bls381_g2_op_batch.argtypes = [vp, ctypes.c_int, u64p, u64p, u64p, u8p, sz]
     lib.bls381_groth16_pairing_batch.argtypes = [vp, u64p, u64p, u64p, u64p, u8p, sz]
     lib.bls381_groth16_pairing_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     lib.bls381_prepared_pairing_batch.argtypes = [vp, u64p, u64p, u64p, sz, sz, u64p, u8p, sz]
@@ -291,6 +296,25 @@ class Engine:
         flags = np.zeros(n, dtype=np.uint8)
         self._check(self.lib.bls381_g2_prepare_batch(self._ctx, pa, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                                      flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_g2_prepare_batch")
+        return out, flags
+
+    def point_op(self, group, op, a, b=None):
+        """bls381_g1_op_batch (group 1, 18 u64 per point) / bls381_g2_op_batch (group 2, 36 u64 per point) on Jacobian points.
+        Returns (out, flags); predicates (POINT_EQ, POINT_IS_ON_CURVE) answer in flags & FLAG_TRUE and return out = None."""
+        w = 18 if group == 1 else 36
+        a, pa = _u64(a)
+        n = a.size // w
+        assert a.size == n * w, "ragged input"
+        pb = None
+        if b is not None:
+            b, pb = _u64(b)
+            assert b.size == a.size
+        predicate = op in (POINT_EQ, POINT_IS_ON_CURVE)
+        out = None if predicate else np.zeros(n * w, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.bls381_g1_op_batch if group == 1 else self.lib.bls381_g2_op_batch
+        self._check(fn(self._ctx, op, pa, pb, None if predicate else out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                       flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_g%d_op_batch" % group)
         return out, flags
 
     def line_ref_opt(self, q1_jac, q2_jac, p_jac):

@@ -213,6 +213,15 @@ class HostSim:
         assert self.lib.hostsim_witness_sqrt(op, _ptr(x), _ptr(sgn, ctypes.c_uint8), _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n)) == 0
         return out, flags
 
+    def point_op(self, group, op, a, b=None, form=IO_ARK_MONT):
+        w = 18 if group == 1 else 36
+        n = len(a) // w
+        out = np.zeros(n * w, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        rc = self.lib.hostsim_point_op(group, op, form, _ptr(a), _ptr(b), _ptr(out), flags.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n))
+        assert rc == 0
+        return out, flags
+
     def line_ref_opt(self, q1, q2, p, form=IO_ARK_MONT):
         n = len(q1) // 36
         out = np.zeros(n * 24, dtype=np.uint64)

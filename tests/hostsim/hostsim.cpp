@@ -173,6 +173,20 @@ int hostsim_line_ref_opt(int form, const uint64_t* q1, const uint64_t* q2, const
   return 0;
 }
 
+// bls381_g1_op_batch (group 1) / bls381_g2_op_batch (group 2), same element routine as k_point_op
+int hostsim_point_op(int group, int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    if (group == 1) {
+      G1Jac x, y, r; jac_load(x, a + 18 * i, form); if (b) jac_load(y, b + 18 * i, form); else y = x;
+      flags[i] = point_op(op, x, y, r); jac_store(out + 18 * i, r, form);
+    } else {
+      G2Jac x, y, r; jac_load(x, a + 36 * i, form); if (b) jac_load(y, b + 36 * i, form); else y = x;
+      flags[i] = point_op(op, x, y, r); jac_store(out + 36 * i, r, form);
+    }
+  }
+  return 0;
+}
+
 int hostsim_fp_pow(int form, const uint64_t* a, const uint64_t* e, int nwords, uint64_t* out, size_t n) {
   for (size_t i = 0; i < n; ++i) fp_store(out + 6 * i, fp_pow_words(fp_load(a + 6 * i, form), e, nwords), form);
   return 0;

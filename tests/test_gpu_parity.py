@@ -91,6 +91,21 @@ def test_pairing_same_bits_with_and_without_batched_inversion(engine, coracle):
         engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, 1)
 
 
+def test_point_surface_g1_g2(engine):
+    """bls381_g1_op_batch / bls381_g2_op_batch against the oracle (same cases as the host simulation): the arkworks group
+    law of opt.rs:93,98 with its fallbacks, normalisation, equality across representatives, curve membership."""
+    import point_cases
+    for group in (1, 2):
+        point_cases.check(engine.point_op, group)
+    # argument checking: predicates need flags, ADD needs b (through the raw ABI)
+    import ctypes
+    a = point_cases.encode(2, point_cases.build(2)[point_cases.DOUBLE][0])
+    pa = a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert engine.lib.bls381_g2_op_batch(engine._ctx, B.POINT_ADD, pa, None, pa, None, 4) == 1          # BLS381_E_INVALID
+    assert engine.lib.bls381_g2_op_batch(engine._ctx, B.POINT_IS_ON_CURVE, pa, None, None, None, 4) == 1
+    assert engine.lib.bls381_g2_op_batch(engine._ctx, 9, pa, None, pa, None, 4) == 1
+
+
 def test_tower_identities_kat5(engine):
     """x^2 == x*x and (a+b) c^2 == c^2 a + c^2 b on device (the reference's test_fq12_arithmetic shape)."""
     rng = random.Random(55)

@@ -120,3 +120,15 @@ def test_canonical_io_form(hostsim):
 
 def test_bound_checks_ran(hostsim):
     assert hostsim.lib.hostsim_bound_checks() > 100000
+
+
+def test_point_surface_g1_g2(hostsim):
+    """Jacobian add / double / normalise / equality / on-curve for G1 and G2 (A4 of SURVEY 8a: the arkworks group law at
+    opt.rs:93,98, with its equal-operand, opposite-operand and infinity branches) against the oracle, bit for bit."""
+    import point_cases
+
+    def run(group, op, a, b):
+        out, fl = hostsim.point_op(group, op, a, b)
+        return out, fl
+    for group in (1, 2):
+        point_cases.check(run, group)
