@@ -25,6 +25,9 @@ struct bls381_ctx {
   int fexp_batched_inv = 1;          // BLS381_OPT_FEXP_BATCHED_INVERSION
   uint32_t* raw_scratch = nullptr;   // n x 16 dwords: norms / norm inverses between the final-exponentiation kernels
   size_t raw_scratch_elems = 0;
+  hipEvent_t scratch_done = nullptr; // recorded after the last launch that used raw_scratch
+  hipStream_t scratch_stream = nullptr;
+  bool scratch_used = false;
 };
 
 #define HIP_TRY(ctx, expr)                                        \
@@ -56,7 +59,8 @@ int bls381_create(bls381_ctx** out, int device_id) {
   if (!c) return BLS381_E_NOMEM;
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return BLS381_E_NO_DEVICE;
   }
@@ -72,6 +76,7 @@ void bls381_destroy(bls381_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->raw_scratch) (void)hipFree(c->raw_scratch);
+  if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
   delete c;
 }
 
@@ -135,17 +140,31 @@ struct Timed {
   ~Timed() { (void)hipEventRecord(c->ev1, c->stream); c->timed = true; }
 };
 
-// Device scratch of the split final exponentiation (grow-only, owned by the context; work queued on the stream that
-// still uses an outgrown buffer is drained before it is released).  *out stays nullptr when the option is off.
+// Device scratch of the split final exponentiation: grow-only, owned by the context.  The launches are asynchronous, so
+// a previous call may still be using the buffer: on the same stream the order is implicit; after bls381_set_stream the
+// new stream first waits for the event recorded behind the last user; an outgrown buffer is released only after that
+// user has finished.  *out stays nullptr when the option is off.
 int fexp_scratch(bls381_ctx* c, size_t n, uint32_t** out) {
   *out = nullptr;
   if (!c->fexp_batched_inv) return BLS381_OK;
+  if (c->scratch_used && c->scratch_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->scratch_done, 0));
   if (c->raw_scratch_elems < n) {
-    if (c->raw_scratch) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0; }
+    if (c->raw_scratch) {
+      if (c->scratch_used) HIP_TRY(c, hipEventSynchronize(c->scratch_done));
+      (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0;
+    }
     HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, n * 16 * sizeof(uint32_t)));
     c->raw_scratch_elems = n;
   }
   *out = c->raw_scratch;
+  return BLS381_OK;
+}
+// call after the launches that used the scratch were queued on c->stream
+int fexp_scratch_release(bls381_ctx* c, const uint32_t* scratch) {
+  if (!scratch) return BLS381_OK;
+  HIP_TRY(c, hipEventRecord(c->scratch_done, c->stream));
+  c->scratch_stream = c->stream;
+  c->scratch_used = true;
   return BLS381_OK;
 }
 
@@ -171,6 +190,7 @@ int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k
     if (!bls_launch::multi(k, FE, g1, g2, out, flags, n, c->io_form, c->block, c->stream, scratch)) return BLS381_E_INVALID;
   }
   HIP_TRY(c, hipGetLastError());
+  { const int rc = fexp_scratch_release(c, scratch); if (rc != BLS381_OK) return rc; }
   return BLS381_OK;
 }
 
@@ -184,6 +204,7 @@ int launch_final_exp(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* 
     bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream, scratch);
   }
   HIP_TRY(c, hipGetLastError());
+  { const int rc = fexp_scratch_release(c, scratch); if (rc != BLS381_OK) return rc; }
   return BLS381_OK;
 }
 
@@ -348,6 +369,7 @@ int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, con
       return BLS381_E_INVALID;
   }
   HIP_TRY(c, hipGetLastError());
+  { const int rc = fexp_scratch_release(c, scratch); if (rc != BLS381_OK) return rc; }
   return BLS381_OK;
 }
 

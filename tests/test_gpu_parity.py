@@ -279,6 +279,32 @@ def test_device_pointer_api_on_caller_stream(engine, coracle):
     assert torch.equal(out, out2)
 
 
+def test_final_exp_scratch_across_streams_and_regrowth(engine):
+    """The split final exponentiation parks norms in context-owned device scratch and every launch is asynchronous: a
+    second call on ANOTHER stream, with a larger batch (the scratch is re-allocated while the first call may still be
+    running), must neither race with nor corrupt the first."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n1, n2 = 4096, 12288
+    g1, g2 = synthetic_batch(n2, seed=99, jacobian=False, pool=32)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev); d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    ref = torch.zeros(n2 * 72, dtype=torch.int64, device=dev)
+    engine.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), 1, ref.data_ptr(), 0, n2)
+    engine.sync()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    o1 = torch.zeros(n1 * 72, dtype=torch.int64, device=dev); o2 = torch.zeros(n2 * 72, dtype=torch.int64, device=dev)
+    e2 = B.Engine(0)                                      # fresh context: its scratch starts empty and must grow twice
+    try:
+        e2.set_stream(s1.cuda_stream)
+        e2.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), 1, o1.data_ptr(), 0, n1)
+        e2.set_stream(s2.cuda_stream)
+        e2.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), 1, o2.data_ptr(), 0, n2)
+        s1.synchronize(); s2.synchronize()
+    finally:
+        e2.set_stream(None)
+    assert torch.equal(o1, ref[: n1 * 72]) and torch.equal(o2, ref)
+
+
 def test_witness_generator_backend(engine):
     """bls381_witness_*: the run_once hooks (fq12/fq6/fq2 inverse, fq/fq2 sqrt with sgn0 fix-up) vs the oracle."""
     from witness_cases import cases, enc_can, as_u32
