@@ -1,6 +1,6 @@
 // libbls381_hip.so -- the C ABI of include/bls381_hip.h (contexts, staging, launches; kernels live in k_*.hip).
 //
-// One pairing per lane; a workgroup is `block` lanes (default one 64-lane wave).  Each entry point cites
+// One pairing per lane pair (fp2_pair.cuh); a workgroup is `block` lanes (default one 64-lane wave = 32 pairings).  Each entry point cites
 // the reference item it replaces in include/bls381_hip.h.  There is NO host fallback: without a HIP device
 // bls381_create fails with BLS381_E_NO_DEVICE.
 #include <hip/hip_runtime.h>

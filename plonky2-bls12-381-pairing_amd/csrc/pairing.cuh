@@ -19,6 +19,12 @@
 #define BLS_INLINE_PAIRS_MAX (BLS_LANES == 2 ? 3 : 1)
 #endif
 
+// Hook at the top of every Miller-loop iteration (experiments: e.g. a workgroup barrier that keeps the waves of a CU
+// within one iteration of each other so that they share instruction-cache lines).  Empty by default.
+#ifndef BLS_MILLER_ITERATION_HOOK
+#define BLS_MILLER_ITERATION_HOOK() ((void)0)
+#endif
+
 namespace bls {
 
 enum : uint8_t { FLAG_DEN_ZERO = 1, FLAG_INFINITY = 2 };
@@ -325,6 +331,7 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
   for (int b = 61; b >= -1; --b) {
     const bool last = b < 0;
     const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    BLS_MILLER_ITERATION_HOOK();
     for (int pass = 0; pass < passes; ++pass) {
       if constexpr (N_PAIRS <= BLS_INLINE_PAIRS_MAX) {
 #pragma unroll

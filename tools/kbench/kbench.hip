@@ -6,6 +6,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifdef KB_SYNC
+#define BLS_MILLER_ITERATION_HOOK() __syncthreads()
+#endif
+#ifdef KB_HOOK
+#define BLS_MILLER_ITERATION_HOOK() KB_HOOK
+#endif
 #include "pairing.cuh"
 using namespace bls;
 #ifndef KB_LB
@@ -21,8 +27,12 @@ using namespace bls;
 
 __global__ void __launch_bounds__(KB_LB) KB_ATTR
 k_pair(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out, size_t n) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
+#if defined(KB_SYNC) || defined(KB_CLAMP)
+  if (i >= n) i = n - 1;             // every lane reaches the barriers (n is a multiple of the block in this tool)
+#else
   if (i >= n) return;
+#endif
   G1Aff p[1]; G2Aff q[1]; bool skip[1];
   bool i1, i2;
   p[0] = g1_aff_load(g1 + 12 * i, 0, i1);
