@@ -187,6 +187,19 @@ def test_mode_b_vs_c_oracle_batch(engine, coracle, k):
     assert np.array_equal(outm, expm)
 
 
+def test_pairing_equals_textbook_ate_cubed_on_device(engine):
+    """The GPU pairing against tests/textbook_ate.py directly (untwisted Q, affine lines over Fp12, one big power) -- a
+    check that shares no curve or final-exponentiation formula with the kernels or with oracle/."""
+    import textbook_ate as T
+    from blsutil import point_pool
+    p1, p2 = point_pool(16)
+    idx = [(0, 0), (5, 9), (15, 2)]
+    g1 = enc_fps([c for i, _ in idx for c in flat_g1_aff(p1[i])]); g2 = enc_fps([c for _, j in idx for c in flat_g2_aff(p2[j])])
+    out, fl = engine.multi_pairing(g1, g2, 1)
+    cube = lambda a: O.fp12_mul(O.fp12_mul(a, a), a)
+    assert dec_fp12s(out) == [cube(T.textbook_ate(p1[i], p2[j])) for i, j in idx] and not fl.any()
+
+
 def test_bilinearity_on_device(engine):
     """e(aP, bQ) == e(P, Q)^(ab) == e(abP, Q), computed on the GPU."""
     a, b = 11, 23

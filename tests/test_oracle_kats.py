@@ -95,6 +95,37 @@ def test_mode_b_invariants():
     assert O.fp12_is_one(O.multi_miller_loop_literal([(O.G1_GEN, O.G2_GEN)]))
 
 
+def test_final_exponentiation_is_the_closed_form_power():
+    """The whole easy-part / hard-part chain of src/fields_as_trees/miller_loop.rs:128-178 (Frobenius maps, five
+    cyclotomic exponentiations, conjugations) equals ONE big-integer power: f ^ (3 (p^12 - 1) / r).  The factor 3 is the
+    hard part's (x-1)^2 (x+p)(x^2+p^2-1) + 3 decomposition."""
+    import random
+    rng = random.Random(12)
+    e = 3 * ((O.P ** 12 - 1) // O.R_ORDER)
+    for _ in range(2):
+        f = O.fp12_unflatten([rng.randrange(O.P) for _ in range(12)])
+        assert O.final_exponentiation(f) == O.fp12_pow(f, e)
+
+
+def test_mode_b_equals_textbook_ate_pairing_cubed():
+    """Independent pin for Mode B (the reference holds no pairing vector): a textbook ate pairing -- untwisted Q, affine
+    chord-and-tangent lines over Fp12, one big power (tests/textbook_ate.py; no formula shared with Alg. 26/27, the sparse
+    products or the cyclotomic chain) -- cubed equals the oracle's pairing, on the generators and on other multiples;
+    the Miller values themselves differ only by a factor the final exponentiation kills."""
+    import textbook_ate as T
+    from blsutil import point_pool
+    p1, p2 = point_pool(16)
+    cube = lambda a: O.fp12_mul(O.fp12_mul(a, a), a)
+    for i, j in ((0, 0), (3, 1), (7, 12)):
+        assert O.pairing(p1[i], p2[j]) == cube(T.textbook_ate(p1[i], p2[j])), (i, j)
+    # Miller-only: reference-style f (conjugated, x < 0) times the textbook f_{|x|} is killed by the final exponentiation
+    m = O.fp12_mul(O.miller_loop(p1[0], p2[0]), T.miller_function(p1[0], p2[0]))
+    assert O.fp12_is_one(O.final_exponentiation(m))
+    # k = 2 product
+    prod = O.fp12_mul(T.textbook_ate(p1[1], p2[2]), T.textbook_ate(p1[4], p2[3]))
+    assert O.multi_pairing([(p1[1], p2[2]), (p1[4], p2[3])]) == cube(prod)
+
+
 def test_golden_files_reproduce():
     """The committed fixtures are what the oracle computes today (guards against silent oracle drift)."""
     for c in load_golden("mode_a.json")["cases"][:4]:
