@@ -52,8 +52,8 @@ def main():
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fexp-batched-inv", type=int, choices=[0, 1], default=1,
-                    help="1 (library default): batch-wide simultaneous inversion under the final exponentiation; 0: self-contained kernel")
+    ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2], default=-1,
+                    help="BLS381_OPT_FEXP_MODE: 0 self-contained kernel, 1 batched inversion, 2 staged (compressed squarings); -1 = library default")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
                     "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
     ap.add_argument("--exchange", action="store_true", help="after the timed region, run the one-rank-owns-the-batch flow once: "
@@ -89,8 +89,11 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.block:
         eng.set_option(B.OPT_BLOCK_SIZE, args.block)
-    eng.set_option(B.OPT_FEXP_BATCHED_INVERSION, args.fexp_batched_inv)
-    fexp_kernels = "k_fexp_norm + k_fp_batch_inv + k_final_exp_given" if args.fexp_batched_inv else "k_final_exp"
+    if args.fexp_mode >= 0:
+        eng.set_option(B.OPT_FEXP_MODE, args.fexp_mode)
+    fexp_mode = eng.get_option(B.OPT_FEXP_MODE)
+    fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
+                    "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>)")[fexp_mode]
 
     g16 = args.workload in ("groth16", "groth16_prepared")
     k = 3 if g16 else 1

@@ -60,10 +60,15 @@ enum {
 };
 
 enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
-       /* 1 (default): the one Fp inversion under each final exponentiation (f^-1 of the easy part,
-        * src/fields_as_trees/miller_loop.rs:175) is taken from a batch-wide simultaneous inversion (three launches,
-        * 64 B of context-owned device scratch per element); 0: one self-contained kernel.  Same output bits. */
-       BLS381_OPT_FEXP_BATCHED_INVERSION = 3 };
+       BLS381_OPT_FEXP_MODE = 3 /* how the final exponentiation (src/fields_as_trees/miller_loop.rs:128-178) is run; same output bits */ };
+enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per element */
+       BLS381_FEXP_BATCHED_INVERSION = 1, /* the Fp inversion under f^-1 (:175) from a batch-wide simultaneous inversion: three launches,
+                                             64 B of context-owned device scratch per element */
+       BLS381_FEXP_STAGED = 2,          /* additionally Karabina-compressed cyclotomic squarings, their decompression denominators
+                                             inverted batch-wide: six stage kernels with an inversion kernel before each,
+                                             ~8.5 KB of context-owned device scratch per element (batches above 2^20 elements
+                                             run in passes of 2^20) */
+       BLS381_FEXP_DEFAULT = BLS381_FEXP_BATCHED_INVERSION };
 enum { BLS381_IO_ARK_MONT = 0, BLS381_IO_CANONICAL = 1 };
 
 /* Fp ops (first-kernel surface).  b may be NULL for unary ops. */

@@ -22,10 +22,16 @@ struct bls381_ctx {
   int fp2_shortcut = 0;
   int block = 64;
   int last_hip = 0;
-  int fexp_batched_inv = 1;          // BLS381_OPT_FEXP_BATCHED_INVERSION
+  int fexp_mode = BLS381_FEXP_DEFAULT;   // BLS381_OPT_FEXP_MODE
   uint32_t* raw_scratch = nullptr;   // n x 16 dwords: norms / norm inverses between the final-exponentiation kernels
   size_t raw_scratch_elems = 0;
+  uint32_t* stage_scratch = nullptr; // staged form: lane-sliced stage values (csrc/fexp_stages.cuh)
+  size_t stage_scratch_bytes = 0;
   hipEvent_t scratch_done = nullptr; // recorded after the last launch that used raw_scratch
+  // staged final exponentiation: the batch runs as two half-batch pipelines on two auxiliary streams, so that the ramp,
+  // tail and stalls of one stage kernel (and the latency-bound inversion kernels) overlap with the other half's work
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, stagger = nullptr, join[2] = {nullptr, nullptr};
   hipStream_t scratch_stream = nullptr;
   bool scratch_used = false;
 };
@@ -60,8 +66,14 @@ int bls381_create(bls381_ctx** out, int device_id) {
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-      hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming) != hipSuccess) {
-    delete c;
+      hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->aux[0], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->stagger, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->join[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->join[1], hipEventDisableTiming) != hipSuccess) {
+    bls381_destroy(c);
     return BLS381_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
@@ -76,7 +88,14 @@ void bls381_destroy(bls381_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->raw_scratch) (void)hipFree(c->raw_scratch);
+  if (c->stage_scratch) (void)hipFree(c->stage_scratch);
   if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
+  for (int i = 0; i < 2; ++i) {
+    if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+    if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+  }
+  if (c->fork) (void)hipEventDestroy(c->fork);
+  if (c->stagger) (void)hipEventDestroy(c->stagger);
   delete c;
 }
 
@@ -90,7 +109,9 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
     case BLS381_OPT_BLOCK_SIZE:
       if (value != 64 && value != 128 && value != 256) return BLS381_E_INVALID;
       c->block = value; return BLS381_OK;
-    case BLS381_OPT_FEXP_BATCHED_INVERSION: c->fexp_batched_inv = value ? 1 : 0; return BLS381_OK;
+    case BLS381_OPT_FEXP_MODE:
+      if (value < BLS381_FEXP_SELF_CONTAINED || value > BLS381_FEXP_STAGED) return BLS381_E_INVALID;
+      c->fexp_mode = value; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -101,7 +122,7 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_IO_FORM: *value = c->io_form; return BLS381_OK;
     case BLS381_OPT_REF_OPT_FP2_SHORTCUT: *value = c->fp2_shortcut; return BLS381_OK;
     case BLS381_OPT_BLOCK_SIZE: *value = c->block; return BLS381_OK;
-    case BLS381_OPT_FEXP_BATCHED_INVERSION: *value = c->fexp_batched_inv; return BLS381_OK;
+    case BLS381_OPT_FEXP_MODE: *value = c->fexp_mode; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -140,31 +161,69 @@ struct Timed {
   ~Timed() { (void)hipEventRecord(c->ev1, c->stream); c->timed = true; }
 };
 
-// Device scratch of the split final exponentiation: grow-only, owned by the context.  The launches are asynchronous, so
-// a previous call may still be using the buffer: on the same stream the order is implicit; after bls381_set_stream the
-// new stream first waits for the event recorded behind the last user; an outgrown buffer is released only after that
-// user has finished.  *out stays nullptr when the option is off.
-int fexp_scratch(bls381_ctx* c, size_t n, uint32_t** out) {
-  *out = nullptr;
-  if (!c->fexp_batched_inv) return BLS381_OK;
+// Device scratch of the multi-kernel final exponentiations: grow-only, owned by the context.  The launches are
+// asynchronous, so a previous call may still be using the buffers: on the same stream the order is implicit; after
+// bls381_set_stream the new stream first waits for the event recorded behind the last user; an outgrown buffer is released
+// only after that user has finished.
+constexpr size_t FEXP_CHUNK = (size_t)1 << 20;      // staged form: elements per pass (bounds the stage scratch at ~8.9 GB)
+constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14; // staged form: from this many elements on, two half-batch pipelines
+
+struct FexpPlan { uint32_t* raw = nullptr; uint32_t* stage = nullptr; size_t chunk = 0; };
+
+int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
+  *plan = FexpPlan();
+  if (c->fexp_mode == BLS381_FEXP_SELF_CONTAINED) return BLS381_OK;
   if (c->scratch_used && c->scratch_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->scratch_done, 0));
-  if (c->raw_scratch_elems < n) {
-    if (c->raw_scratch) {
-      if (c->scratch_used) HIP_TRY(c, hipEventSynchronize(c->scratch_done));
-      (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0;
+  const size_t chunk = (c->fexp_mode == BLS381_FEXP_STAGED && n > FEXP_CHUNK) ? FEXP_CHUNK : n;
+  const size_t stage_bytes = (c->fexp_mode == BLS381_FEXP_STAGED) ? bls_launch::fexp_stage_scratch_bytes(chunk) : 0;
+  if (c->raw_scratch_elems < chunk || c->stage_scratch_bytes < stage_bytes) {
+    if (c->scratch_used) HIP_TRY(c, hipEventSynchronize(c->scratch_done));
+    if (c->raw_scratch_elems < chunk) {
+      if (c->raw_scratch) { (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0; }
+      HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, chunk * 16 * sizeof(uint32_t)));
+      c->raw_scratch_elems = chunk;
     }
-    HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, n * 16 * sizeof(uint32_t)));
-    c->raw_scratch_elems = n;
+    if (c->stage_scratch_bytes < stage_bytes) {
+      if (c->stage_scratch) { (void)hipFree(c->stage_scratch); c->stage_scratch = nullptr; c->stage_scratch_bytes = 0; }
+      HIP_TRY(c, hipMalloc((void**)&c->stage_scratch, stage_bytes));
+      c->stage_scratch_bytes = stage_bytes;
+    }
   }
-  *out = c->raw_scratch;
+  plan->raw = c->raw_scratch;
+  plan->stage = (c->fexp_mode == BLS381_FEXP_STAGED) ? c->stage_scratch : nullptr;
+  plan->chunk = chunk;
   return BLS381_OK;
 }
-// call after the launches that used the scratch were queued on c->stream
-int fexp_scratch_release(bls381_ctx* c, const uint32_t* scratch) {
-  if (!scratch) return BLS381_OK;
-  HIP_TRY(c, hipEventRecord(c->scratch_done, c->stream));
-  c->scratch_stream = c->stream;
-  c->scratch_used = true;
+// the final exponentiation of `n` elements in the context's mode, queued on c->stream (in place allowed)
+int fexp_launch(bls381_ctx* c, const FexpPlan& plan, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
+  if (plan.stage && n >= FEXP_PIPELINE_MIN) {
+    // two half-batch pipelines: fork from the caller's stream, each half on its own stream and its own half of the
+    // scratch, join back.  Halves are cut at a multiple of 128 elements so that every launch shape fits its scratch half.
+    const size_t half_chunk = plan.chunk / 2 / 128 * 128;
+    const size_t n0 = (n / 2 + 127) / 128 * 128 < n ? (n / 2 + 127) / 128 * 128 : n;
+    const size_t stage_dwords_half = bls_launch::fexp_stage_scratch_bytes(half_chunk) / sizeof(uint32_t);
+    HIP_TRY(c, hipEventRecord(c->fork, c->stream));
+    for (int h = 0; h < 2; ++h) {
+      const size_t first = h ? n0 : 0, cnt = h ? n - n0 : n0;
+      // the second half starts when the first half's stage 1 is through: from then on the two pipelines are half a
+      // beat apart, and each one's inversion kernels, ramps and tails fall into the other's stage kernels
+      HIP_TRY(c, hipStreamWaitEvent(c->aux[h], h ? c->stagger : c->fork, 0));
+      if (cnt) bls_launch::final_exp_staged(in + 72 * first, out + 72 * first, flags ? flags + first : nullptr, cnt, c->io_form, c->block,
+                                            c->aux[h], plan.raw + (size_t)h * half_chunk * 16, plan.stage + (size_t)h * stage_dwords_half, half_chunk,
+                                            h ? nullptr : c->stagger);
+      HIP_TRY(c, hipEventRecord(c->join[h], c->aux[h]));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join[h], 0));
+    }
+  } else if (plan.stage) {
+    bls_launch::final_exp_staged(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw, plan.stage, plan.chunk, nullptr);
+  } else {
+    bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw);
+  }
+  if (plan.raw) {                                     // mark the scratch busy until this point of the stream
+    HIP_TRY(c, hipEventRecord(c->scratch_done, c->stream));
+    c->scratch_stream = c->stream;
+    c->scratch_used = true;
+  }
   return BLS381_OK;
 }
 
@@ -183,28 +242,31 @@ template <bool FE>
 int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  uint32_t* scratch = nullptr;
-  if (FE) { const int rc = fexp_scratch(c, n, &scratch); if (rc != BLS381_OK) return rc; }
+  FexpPlan plan;
+  if (FE) { const int rc = fexp_acquire(c, n, &plan); if (rc != BLS381_OK) return rc; }
+  int rc = BLS381_OK;
   {
     Timed t(c);
-    if (!bls_launch::multi(k, FE, g1, g2, out, flags, n, c->io_form, c->block, c->stream, scratch)) return BLS381_E_INVALID;
+    if (!bls_launch::multi(k, g1, g2, out, flags, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
+    if (FE) rc = fexp_launch(c, plan, out, out, nullptr, n);
   }
+  if (rc != BLS381_OK) return rc;
   HIP_TRY(c, hipGetLastError());
-  { const int rc = fexp_scratch_release(c, scratch); if (rc != BLS381_OK) return rc; }
   return BLS381_OK;
 }
 
 int launch_final_exp(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  uint32_t* scratch = nullptr;
-  { const int rc = fexp_scratch(c, n, &scratch); if (rc != BLS381_OK) return rc; }
+  FexpPlan plan;
+  { const int rc = fexp_acquire(c, n, &plan); if (rc != BLS381_OK) return rc; }
+  int rc;
   {
     Timed t(c);
-    bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream, scratch);
+    rc = fexp_launch(c, plan, in, out, flags, n);
   }
+  if (rc != BLS381_OK) return rc;
   HIP_TRY(c, hipGetLastError());
-  { const int rc = fexp_scratch_release(c, scratch); if (rc != BLS381_OK) return rc; }
   return BLS381_OK;
 }
 
@@ -361,15 +423,17 @@ int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, con
   if (!c || n_var > 1 || n_fixed < 1 || n_fixed > 2 || (n && (!g1_aff || (n_var && !g2_var) || !prepared_fixed || !out_gt))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  uint32_t* scratch = nullptr;
-  { const int rc = fexp_scratch(c, n, &scratch); if (rc != BLS381_OK) return rc; }
+  FexpPlan plan;
+  { const int rc = fexp_acquire(c, n, &plan); if (rc != BLS381_OK) return rc; }
+  int rc;
   {
     Timed t(c);
-    if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream, scratch))
+    if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
       return BLS381_E_INVALID;
+    rc = fexp_launch(c, plan, out_gt, out_gt, nullptr, n);
   }
+  if (rc != BLS381_OK) return rc;
   HIP_TRY(c, hipGetLastError());
-  { const int rc = fexp_scratch_release(c, scratch); if (rc != BLS381_OK) return rc; }
   return BLS381_OK;
 }
 

@@ -1,0 +1,202 @@
+// Staged final exponentiation with Karabina-compressed cyclotomic squarings (MI355X-side algorithm; same field values
+// as src/fields_as_trees/miller_loop.rs:128-178, hence the same output bits).
+//
+// After the easy part every value lives in the cyclotomic subgroup, where a squaring needs only four of the six Fp2
+// coordinates (z2..z5 in the naming of `cyclotomic_square`, miller_loop.rs:46-104): the Granger-Scott formulas for
+// z2', z3', z4', z5' never read z0, z1, so dropping that pair saves one of the three Fp4 squarings -- a third of the
+// work of the 5 x 63 squarings that are ~78 % of the final exponentiation.  Getting z0, z1 back (Karabina 2013),
+//     z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)        [ z1 = 2 z4 z5 / z3  when z2 = 0 ]
+//     z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1,
+// costs a division, i.e. one Fp inversion per exponentiation by |x| -- more than the squarings save when every lane pays
+// its own Fermat inversion.  A GPU batch does not have to: the exponentiation is cut at the inversion, the Fp norms of
+// all elements go through ONE simultaneous inversion (k_fp_batch_inv, Montgomery's trick), and the next kernel resumes.
+// f^|x| = f^(2^63) f^(2^62) f^(2^60) f^(2^57) f^(2^48) f^(2^16): the compressed chain is walked once, the six marked
+// powers are parked in scratch, their six denominators share one inversion, then five multiplications.
+//
+// Six stage kernels (k_fexp.hip) with a batch inversion between consecutive ones:
+//   1  f^-1 from the supplied norm inverse, easy part -> t2; t1 = conj(t2^2);               start exp(t2)
+//   2  t3 = exp(t2); t4 = t3^2; t5 = t1 t3; u = conj(t5) t2;                                 start exp(t5)
+//   3  t1' = exp(t5); v = frob^3(t1' t2);                                                    start exp(t1')
+//   4  t0 = exp(t1'); w = frob^2(t3 t0) v;                                                   start exp(t0)
+//   5  t6 = exp(t0) t4; w = w frob(t6 conj(t2));                                             start exp(t6)
+//   6  result = w (exp(t6) u)
+// which is f_conversion (:128-164) regrouped so that each value is parked at most once.
+#pragma once
+#include "tower.cuh"
+
+namespace bls {
+
+struct Fp12C { Fp2R z2, z3, z4, z5; };       // compressed cyclotomic element
+
+BLS_HD Fp12C compress(const Fp12R& f) { return Fp12C{f.c1.c0, f.c0.c2, f.c0.c1, f.c1.c2}; }
+
+// the z2..z5 half of cyclotomic_square (tower.cuh), verbatim
+BLS_HD Fp12C compressed_square(const Fp12C& g) {
+  const auto B = fp4_square(g.z2, g.z3);
+  const auto C = fp4_square(g.z4, g.z5);
+  const auto n4 = add(dbl(sub(B.a, g.z4)), B.a);
+  const auto n5 = add(dbl(add(B.b, g.z5)), B.b);
+  const auto t0 = mul_xi(fit<1, 2>(C.b));
+  const auto n2 = add(dbl(add(t0, g.z2)), t0);
+  const auto n3 = add(dbl(sub(C.a, g.z3)), C.a);
+  return Fp12C{fit<1, 2>(n2), fit<1, 2>(n3), fit<1, 2>(n4), fit<1, 2>(n5)};
+}
+
+// denominator of z1 (4 z2, or z3 when z2 = 0) with zero replaced by one, and whether it was zero: then z1 = 0, which
+// is right for the only such element that occurs, the identity (z2 = z3 = z4 = z5 = 0 -> z1 = 0, z0 = 1)
+BLS_HD Fp2R decompress_den(const Fp12C& g, bool& was_zero) {
+  const Fp2R d = select(is_zero(g.z2), g.z3, Fp2R(fit<1, 2>(dbl(dbl(g.z2)))));
+  was_zero = is_zero(d);
+  return select(was_zero, Fp2R(fp2_one()), d);
+}
+
+BLS_HD Fp12R decompress(const Fp12C& g, const Fp2R& den_inv) {
+  Fp2R num;
+  if (is_zero(g.z2)) {
+    num = fit<1, 2>(dbl(mul(g.z4, g.z5)));
+  } else {
+    const Fp2R s4 = sqr(g.z4);
+    num = fit<1, 2>(sub(add(mul_xi(sqr(g.z5)), add(dbl(s4), s4)), dbl(g.z3)));
+  }
+  const Fp2R z1 = mul(num, den_inv);
+  const Fp2R m34 = mul(g.z3, g.z4);
+  const auto inner = sub(add(dbl(sqr(z1)), mul(g.z2, g.z5)), add(dbl(m34), m34));
+  const Fp2R z0 = fit<1, 2>(add(mul_xi(fit<1, 2>(inner)), fp2_one()));
+  return Fp12R(Fp6R(z0, g.z4, g.z3), Fp6R(g.z2, z1, g.z5));
+}
+
+// ------------------------------------------------------------------------------------------ scratch layout
+// Per element, in units of Fp2 values inside a LaneScratch (fp.cuh): six Fq12 slots, the six compressed powers of the
+// running exponentiation, and the prefix products of their denominators.
+enum : int { FX_T2 = 0, FX_A = 1, FX_T3 = 2, FX_T4 = 3, FX_U = 4, FX_W = 5, FX_SLOTS = 6 };
+constexpr int FX_COMP_BASE = FX_SLOTS * 6;
+constexpr int FX_PRE_BASE = FX_COMP_BASE + 6 * 4;
+constexpr int FX_FP2_TOTAL = FX_PRE_BASE + 6;                                    // 66 Fp2 per element
+constexpr int FX_DWORDS_PER_LANE = FX_FP2_TOTAL * SCRATCH_FP_PER_FP2 * 16;       // 16 dwords per parked Fp
+
+struct FexpScratch {
+  LaneScratch ls;          // stage values, lane-sliced
+  uint32_t* norm_raw;      // RAW_FP_STRIDE dwords per element: norm out / norm inverse in (k_fp_batch_inv in between)
+  size_t elem;
+};
+
+BLS_HD void fx_put12(const LaneScratch& s, int slot, const Fp12R& a) {
+  fp2_scratch_put(s, slot * 6 + 0, a.c0.c0); fp2_scratch_put(s, slot * 6 + 1, a.c0.c1); fp2_scratch_put(s, slot * 6 + 2, a.c0.c2);
+  fp2_scratch_put(s, slot * 6 + 3, a.c1.c0); fp2_scratch_put(s, slot * 6 + 4, a.c1.c1); fp2_scratch_put(s, slot * 6 + 5, a.c1.c2);
+}
+BLS_HD Fp12R fx_get12(const LaneScratch& s, int slot) {
+  return Fp12R(Fp6R(fp2_scratch_get(s, slot * 6 + 0), fp2_scratch_get(s, slot * 6 + 1), fp2_scratch_get(s, slot * 6 + 2)),
+               Fp6R(fp2_scratch_get(s, slot * 6 + 3), fp2_scratch_get(s, slot * 6 + 4), fp2_scratch_get(s, slot * 6 + 5)));
+}
+BLS_HD void fx_putc(const LaneScratch& s, int m, const Fp12C& g) {
+  fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 0, g.z2); fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 1, g.z3);
+  fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 2, g.z4); fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 3, g.z5);
+}
+BLS_HD Fp12C fx_getc(const LaneScratch& s, int m) {
+  return Fp12C{fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 0), fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 1),
+               fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 2), fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 3)};
+}
+
+// ------------------------------------------------------------------------------------------ one exponentiation, in two halves
+// bits of |x| = 0xd201000000010000 above bit 0: the powers f^(2^k) that make up f^|x|
+constexpr uint64_t FX_MARKS = BLS_X_PARAM;
+static_assert(FX_MARKS == ((1ull << 63) | (1ull << 62) | (1ull << 60) | (1ull << 57) | (1ull << 48) | (1ull << 16)), "six marked powers");
+
+// first half: walk the compressed squaring chain, park the six marked powers and the prefix products of their
+// denominators, leave the Fp norm of the full denominator product for the batch inversion
+BLS_HD_NOINLINE void fexp_start_exp(const Fp12R& x, const FexpScratch& sc) {
+  Fp12C g = compress(x);
+  Fp2R prod = Fp2R(fp2_one());
+  int m = 0;
+  for (int k = 1; k <= 63; ++k) {
+    g = compressed_square(g);
+    if ((FX_MARKS >> k) & 1ull) {
+      fx_putc(sc.ls, m, g);
+      fp2_scratch_put(sc.ls, FX_PRE_BASE + m, prod);
+      bool z;
+      const Fp2R d = decompress_den(g, z);
+      prod = mul(prod, d);
+      ++m;
+    }
+  }
+  const FpR nrm = fp2_norm(prod);
+  if (lane_part() == 0) raw_fp_store(sc.norm_raw + sc.elem * RAW_FP_STRIDE, nrm);
+}
+
+// second half: conj(x^|x|) from the parked powers and the inverse of the norm (== cyclotomic_exp(x), tower.cuh)
+BLS_HD_NOINLINE Fp12R fexp_finish_exp(const FexpScratch& sc) {
+  const FpR norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
+  // inverse of the product of all six denominators; peel one denominator per step, last power first
+  Fp2R prod = fp2_scratch_get(sc.ls, FX_PRE_BASE + 5);
+  {
+    bool z;
+    prod = mul(prod, decompress_den(fx_getc(sc.ls, 5), z));
+  }
+  Fp2R run = fp2_inv_given(prod, norm_inv);
+  Fp12R acc;
+  for (int m = 5; m >= 0; --m) {
+    const Fp12C g = fx_getc(sc.ls, m);
+    bool z;
+    const Fp2R d = decompress_den(g, z);
+    const Fp2R pre = fp2_scratch_get(sc.ls, FX_PRE_BASE + m);
+    const Fp2R dinv = select(z, Fp2R(fp2_zero()), mul(run, pre));
+    run = mul(run, d);
+    const Fp12R v = decompress(g, dinv);
+    acc = (m == 5) ? v : mul_call(acc, v);
+  }
+  return fit<1, 2>(conj(acc));
+}
+
+// ------------------------------------------------------------------------------------------ the six stages
+BLS_HD Fp12R frobenius_n(const Fp12R& a, int n) {
+  Fp12R r = a;
+  for (int i = 0; i < n; ++i) r = frobenius_call(r);
+  return r;
+}
+
+BLS_HD void fexp_stage1(const Fp12R& f, const FexpScratch& sc) {
+  const FpR f_norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
+  const Fp12R f_inv = fp12_inv_given_call(f, f_norm_inv);
+  Fp12R t2 = mul_call(fit<1, 2>(conj(f)), f_inv);                       // :168-175, :133
+  t2 = mul_call(frobenius_n(t2, 2), t2);                                // :135-136
+  const Fp12R t1 = fit<1, 2>(conj(cyclotomic_square_call(t2)));         // :137
+  fx_put12(sc.ls, FX_T2, t2);
+  fx_put12(sc.ls, FX_A, t1);
+  fexp_start_exp(t2, sc);
+}
+BLS_HD void fexp_stage2(const FexpScratch& sc) {
+  const Fp12R t3 = fexp_finish_exp(sc);
+  const Fp12R t4 = cyclotomic_square_call(t3);
+  const Fp12R t5 = mul_call(fx_get12(sc.ls, FX_A), t3);
+  const Fp12R u = mul_call(fit<1, 2>(conj(t5)), fx_get12(sc.ls, FX_T2));
+  fx_put12(sc.ls, FX_T3, t3);
+  fx_put12(sc.ls, FX_T4, t4);
+  fx_put12(sc.ls, FX_U, u);
+  fexp_start_exp(t5, sc);
+}
+BLS_HD void fexp_stage3(const FexpScratch& sc) {
+  const Fp12R t1 = fexp_finish_exp(sc);
+  const Fp12R v = frobenius_n(mul_call(t1, fx_get12(sc.ls, FX_T2)), 3);
+  fx_put12(sc.ls, FX_A, v);
+  fexp_start_exp(t1, sc);
+}
+BLS_HD void fexp_stage4(const FexpScratch& sc) {
+  const Fp12R t0 = fexp_finish_exp(sc);
+  Fp12R w = frobenius_n(mul_call(fx_get12(sc.ls, FX_T3), t0), 2);
+  w = mul_call(w, fx_get12(sc.ls, FX_A));
+  fx_put12(sc.ls, FX_W, w);
+  fexp_start_exp(t0, sc);
+}
+BLS_HD void fexp_stage5(const FexpScratch& sc) {
+  Fp12R t6 = fexp_finish_exp(sc);
+  t6 = mul_call(t6, fx_get12(sc.ls, FX_T4));
+  const Fp12R y = frobenius_n(mul_call(t6, fit<1, 2>(conj(fx_get12(sc.ls, FX_T2)))), 1);
+  fx_put12(sc.ls, FX_W, mul_call(fx_get12(sc.ls, FX_W), y));
+  fexp_start_exp(t6, sc);
+}
+BLS_HD Fp12R fexp_stage6(const FexpScratch& sc) {
+  const Fp12R t4 = fexp_finish_exp(sc);
+  return mul_call(fx_get12(sc.ls, FX_W), mul_call(t4, fx_get12(sc.ls, FX_U)));
+}
+
+}  // namespace bls

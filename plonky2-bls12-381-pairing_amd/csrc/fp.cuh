@@ -19,6 +19,7 @@
 // Every operation static_asserts that its accumulators cannot overflow, so an unsafe lazy-reduction
 // chain is a compile error, not a wrong answer.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -493,6 +494,7 @@ BLS_HD FpR fp_inv(const Fp<L, V>& a) { return fp_pow_const(a, BLS_P_MINUS_2); }
 // Simultaneous inversion (Montgomery's trick) of N values held by ONE lane: 3 N multiplications and a single
 // fp_inv.  Zeros stay zero and do not disturb their neighbours.  Used to amortise the one Fp inversion under every
 // final exponentiation across elements (k_fp_batch_inv, k_misc.hip).
+constexpr int FP_BATCH_INV_CHUNK = 16;       // values per lane in k_fp_batch_inv (k_misc.hip)
 template <int N>
 BLS_HD void fp_batch_inv(FpR (&x)[N]) {
   FpR pre[N];                                  // pre[i] = x_0 ... x_(i-1), zeros read as one
@@ -525,6 +527,32 @@ BLS_HD void raw_fp_store(uint32_t* p, const FpR& a) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) p[i] = a.l[i];
 }
+
+// Lane-sliced scratch for multi-kernel pipelines (final exponentiation stages): value k of lane `lane` keeps its 14 limbs
+// as four 16-byte quarters at  base[((4 k + q) * lanes + lane) * 4 ..],  so that one store instruction of a wave writes
+// 64 consecutive 16-byte pieces (fully coalesced), whatever the number of values per lane.
+struct LaneScratch {
+  uint32_t* base;
+  size_t lanes, lane;
+  BLS_HD void put(int k, const FpR& a) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t* d = base + (((size_t)(4 * k + q)) * lanes + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = (4 * q + j < NL) ? a.l[4 * q + j] : 0u;
+    }
+  }
+  BLS_HD FpR get(int k) const {
+    FpR r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t* d = base + (((size_t)(4 * k + q)) * lanes + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (4 * q + j < NL) r.l[4 * q + j] = d[j];
+    }
+    return r;
+  }
+};
 
 // Square-root candidate a^((p+1)/4) (p = 3 mod 4); the caller checks candidate^2 == a.
 template <int L, int V>

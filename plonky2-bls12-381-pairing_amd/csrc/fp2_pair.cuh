@@ -186,6 +186,11 @@ BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
   return fp2_inv_given(a, fp_inv(fp2_norm(a)));
 }
 
+// Fp2 number `idx` of this element in a LaneScratch: each lane of the pair keeps its own coefficient (one Fp per Fp2)
+constexpr int SCRATCH_FP_PER_FP2 = 1;
+BLS_HD void fp2_scratch_put(const LaneScratch& s, int idx, const Fp2R& a) { s.put(idx, a.v); }
+BLS_HD Fp2R fp2_scratch_get(const LaneScratch& s, int idx) { return Fp2R(s.get(idx)); }
+
 // pair-wide AND of a per-lane predicate
 BLS_HD bool pair_all(bool z) { return (dpp_swap(z ? 1u : 0u) & (z ? 1u : 0u)) != 0; }
 

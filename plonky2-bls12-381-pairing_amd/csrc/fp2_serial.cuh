@@ -106,6 +106,11 @@ BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
   return fp2_inv_given(a, fp_inv(fp2_norm(a)));
 }
 
+// Fp2 number `idx` of this element in a LaneScratch (two Fp per Fp2 on the one lane)
+constexpr int SCRATCH_FP_PER_FP2 = 2;
+BLS_HD void fp2_scratch_put(const LaneScratch& s, int idx, const Fp2R& a) { s.put(2 * idx, a.c0); s.put(2 * idx + 1, a.c1); }
+BLS_HD Fp2R fp2_scratch_get(const LaneScratch& s, int idx) { return Fp2R(s.get(2 * idx), s.get(2 * idx + 1)); }
+
 template <int L, int V>
 BLS_HD bool is_zero(const Fp2<L, V>& a) { return is_zero(a.c0) & is_zero(a.c1); }
 

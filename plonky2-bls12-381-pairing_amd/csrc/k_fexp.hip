@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
 #include "pairing.cuh"
+#include "fexp_stages.cuh"
 #include "launch.h"
 using namespace bls;
 #ifndef BLS_MAX_BLOCK
@@ -49,7 +50,59 @@ k_final_exp_given(const uint64_t* in, uint64_t* out, uint8_t* flags, const uint3
   if (flags && lane_part() == 0) flags[i] = 0;
 }
 
+// Staged form (fexp_stages.cuh): Karabina-compressed squaring chains, one batch-wide inversion between stages.
+// `lanes` = number of lanes of the launch (the lane-sliced scratch is laid out for exactly that many).
+template <int STAGE>
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_fexp_stage(const uint64_t* in, uint64_t* out, uint8_t* flags, uint32_t* __restrict__ scratch, uint32_t* __restrict__ norm_raw,
+             size_t n, size_t lanes, int form) {
+  const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gl / LANES_PER_ELEM;
+  if (i >= n) return;
+  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  if constexpr (STAGE == 1) fexp_stage1(fp12_load(in + 72 * i, form), sc);
+  else if constexpr (STAGE == 2) fexp_stage2(sc);
+  else if constexpr (STAGE == 3) fexp_stage3(sc);
+  else if constexpr (STAGE == 4) fexp_stage4(sc);
+  else if constexpr (STAGE == 5) fexp_stage5(sc);
+  else {
+    fp12_store(out + 72 * i, fexp_stage6(sc), form);
+    if (flags && lane_part() == 0) flags[i] = 0;
+  }
+}
+
 namespace bls_launch {
+size_t fexp_stage_scratch_bytes(size_t n_chunk) {      // for a chunk of n_chunk elements, any supported block size
+  const size_t lanes = (n_chunk * bls::LANES_PER_ELEM + BLS_MAX_BLOCK - 1) / BLS_MAX_BLOCK * BLS_MAX_BLOCK;
+  return lanes * (size_t)FX_DWORDS_PER_LANE * sizeof(uint32_t);
+}
+// Staged final exponentiation over chunks of at most `chunk` elements; raw_scratch: chunk x RAW_FP_STRIDE dwords,
+// stage_scratch: fexp_stage_scratch_bytes(chunk)
+void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
+                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk, hipEvent_t after_first_stage) {
+  for (size_t first = 0; first < n; first += chunk) {
+    const size_t m = (n - first < chunk) ? n - first : chunk;
+    const dim3 grid(grid_for(m, block)), blk(block);
+    const size_t lanes = (size_t)grid.x * block;
+    const uint64_t* ci = in + 72 * first;
+    uint64_t* co = out + 72 * first;
+    uint8_t* cf = flags ? flags + first : nullptr;
+    hipLaunchKernelGGL(k_fexp_norm, grid, blk, 0, s, ci, raw_scratch, m, form);
+    fp_batch_inv_raw(raw_scratch, m, s);
+    hipLaunchKernelGGL(k_fexp_stage<1>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    if (after_first_stage && first == 0) (void)hipEventRecord(after_first_stage, s);
+    fp_batch_inv_raw(raw_scratch, m, s);
+    hipLaunchKernelGGL(k_fexp_stage<2>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    fp_batch_inv_raw(raw_scratch, m, s);
+    hipLaunchKernelGGL(k_fexp_stage<3>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    fp_batch_inv_raw(raw_scratch, m, s);
+    hipLaunchKernelGGL(k_fexp_stage<4>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    fp_batch_inv_raw(raw_scratch, m, s);
+    hipLaunchKernelGGL(k_fexp_stage<5>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    fp_batch_inv_raw(raw_scratch, m, s);
+    hipLaunchKernelGGL(k_fexp_stage<6>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+  }
+}
 // `raw_scratch`: n x RAW_FP_STRIDE dwords of device memory for the split form, or nullptr for the self-contained kernel
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {
   const dim3 grid(grid_for(n, block)), blk(block);

@@ -99,14 +99,13 @@ k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ 
 
 namespace bls_launch {
 bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags,
-              size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {
+              size_t n, int form, int block, hipStream_t s) {
   const dim3 grid((unsigned)((n * bls::LANES_PER_ELEM + G16_BLOCK - 1) / G16_BLOCK)), blk(G16_BLOCK);
   if (nvar == 1 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<1, 2>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
   else if (nvar == 0 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<0, 1>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
   else if (nvar == 1 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<1, 1>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
   else if (nvar == 0 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<0, 2>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
   else return false;
-  final_exp(out, out, nullptr, n, form, block, s, raw_scratch);
   return true;
 }
 }  // namespace bls_launch

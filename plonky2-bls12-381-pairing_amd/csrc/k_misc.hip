@@ -172,7 +172,6 @@ k_point_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ 
 // Simultaneous inversion of n internal-form Fp values in place (raw limbs, RAW_FP_STRIDE dwords apart): one lane per
 // chunk of FP_BATCH_INV_CHUNK values (Montgomery's trick in registers), so the batch pays one Fermat inversion per
 // chunk instead of one per value.  Serves the split final exponentiation (k_fexp.hip).
-constexpr int FP_BATCH_INV_CHUNK = 8;
 __global__ void __launch_bounds__(64)
 k_fp_batch_inv(uint32_t* __restrict__ raw, size_t n) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,12 +196,12 @@ void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s) {
   const size_t chunks = (n + FP_BATCH_INV_CHUNK - 1) / FP_BATCH_INV_CHUNK;
   hipLaunchKernelGGL(k_fp_batch_inv, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, raw, n);
 }
-bool multi(size_t k, bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {
+bool multi(size_t k, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
   switch (k) {
-    case 1: multi_k1(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
-    case 2: multi_k2(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
-    case 3: multi_k3(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
-    case 4: multi_k4(fe, g1, g2, out, flags, n, form, block, s, raw_scratch); return true;
+    case 1: multi_k1(g1, g2, out, flags, n, form, block, s); return true;
+    case 2: multi_k2(g1, g2, out, flags, n, form, block, s); return true;
+    case 3: multi_k3(g1, g2, out, flags, n, form, block, s); return true;
+    case 4: multi_k4(g1, g2, out, flags, n, form, block, s); return true;
     default: return false;
   }
 }

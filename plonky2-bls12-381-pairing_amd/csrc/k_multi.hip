@@ -38,12 +38,10 @@ k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2,
 }
 
 namespace bls_launch {
-// A full pairing is this Miller kernel (one wave per SIMD, ~460 registers per lane, no scratch) followed by the final
+// A full pairing is this Miller kernel (one wave per SIMD, ~460 registers per lane, no scratch) followed by a final
 // exponentiation in place on `out` (k_fexp.hip: its own translation unit, compiled for two waves per SIMD, where it
-// runs ~15 % faster than inside a fused kernel; split around a batch-wide inversion when `raw_scratch` is given).
-// The intermediate Fq12 costs 2 x 576 B of HBM traffic per pairing -- noise.
-void BLS_CAT(multi_k, BLS_K)(bool fe, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {
+// runs ~15 % faster than inside a fused kernel).  The intermediate Fq12 costs 2 x 576 B of HBM traffic per pairing.
+void BLS_CAT(multi_k, BLS_K)(const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
   hipLaunchKernelGGL((k_multi_miller<BLS_K, false>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
-  if (fe) final_exp(out, out, nullptr, n, form, block, s, raw_scratch);
 }
 }  // namespace bls_launch

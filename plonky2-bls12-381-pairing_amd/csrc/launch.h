@@ -6,14 +6,21 @@
 namespace bls_launch {
 void ref_opt(bool fp2_shortcut, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 // k in 1..4; returns false for an unsupported k
-bool multi(size_t k, bool final_exp, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);
-void multi_k1(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t, uint32_t*);
-void multi_k2(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t, uint32_t*);
-void multi_k3(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t, uint32_t*);
-void multi_k4(bool fe, const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t, uint32_t*);
+// Miller loops only; a full pairing = this, then one of the final-exponentiation launches in place on `out`
+bool multi(size_t k, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
+void multi_k1(const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void multi_k2(const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void multi_k3(const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
+void multi_k4(const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int, int, hipStream_t);
 // raw_scratch: n x 16 dwords for the split form (batched inversion), or nullptr for the self-contained kernel
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);
 void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s);
+// staged form (Karabina-compressed squaring chains, csrc/fexp_stages.cuh): processes the batch in chunks of `chunk` elements;
+// raw_scratch: chunk x 16 dwords, stage_scratch: fexp_stage_scratch_bytes(chunk) bytes; `after_first_stage` (optional) is
+// recorded behind the first stage-1 launch so that a second pipeline can start half a beat later
+size_t fexp_stage_scratch_bytes(size_t n_chunk);
+void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
+                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk, hipEvent_t after_first_stage);
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp6_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
@@ -22,8 +29,8 @@ void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uin
 // group 1 = G1 (n x 3 x 6 u64), 2 = G2 (n x 3 x 2 x 6)
 void point_op(int group, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void fill_one(uint64_t* out, size_t n, int form, hipStream_t s);
-// Miller kernel with LDS-staged fixed-G2 coefficients, then the final exponentiation in place
-bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);
+// Miller kernel with LDS-staged fixed-G2 coefficients (no final exponentiation)
+bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void fp_pow(const uint64_t* a, const uint64_t* exp, int nwords, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void g2_prepare(const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void witness_inverse(int op, const uint64_t* x, uint64_t* out, uint8_t* flags, size_t n, int block, hipStream_t s);

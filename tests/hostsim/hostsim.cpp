@@ -7,6 +7,7 @@
 #define BLS_BOUND_CHECK 1
 #include "pairing.cuh"
 #include "witness.cuh"
+#include "fexp_stages.cuh"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,10 +106,10 @@ int hostsim_fp2_op(int op, int form, const uint64_t* a, const uint64_t* b, uint6
 enum { OP12_MUL = 0, OP12_SQR = 1, OP12_INV = 2, OP12_FROBENIUS = 3, OP12_CYC_SQR = 4, OP12_CONJ = 5,
        OP12_CYC_EXP = 6, OP12_FINAL_EXP = 7, OP12_FINAL_EXP_SPLIT = 8 };
 
-// The split final exponentiation exactly as the three kernels run it (k_fexp_norm, k_fp_batch_inv in chunks of eight
+// The split final exponentiation exactly as the three kernels run it (k_fexp_norm, k_fp_batch_inv in chunks of FP_BATCH_INV_CHUNK
 // with the tail padded by ones, k_final_exp_given), raw limbs parked 16 dwords apart in between.
 static int final_exp_split(int form, const uint64_t* a, uint64_t* out, size_t n) {
-  constexpr int CHUNK = 8;
+  constexpr int CHUNK = FP_BATCH_INV_CHUNK;
   uint32_t* raw = (uint32_t*)calloc(n ? n : 1, RAW_FP_STRIDE * sizeof(uint32_t));
   if (!raw) return 2;
   for (size_t i = 0; i < n; ++i) raw_fp_store(raw + i * RAW_FP_STRIDE, fp12_inv_norm_call(fp12_load(a + 72 * i, form)));
@@ -127,8 +128,43 @@ static int final_exp_split(int form, const uint64_t* a, uint64_t* out, size_t n)
   return 0;
 }
 
+static void batch_inv_raw(uint32_t* raw, size_t n) {
+  constexpr int CHUNK = FP_BATCH_INV_CHUNK;
+  for (size_t first = 0; first < n; first += CHUNK) {
+    FpR x[CHUNK];
+    for (int j = 0; j < CHUNK; ++j) x[j] = (first + j < n) ? raw_fp_load(raw + (first + j) * RAW_FP_STRIDE) : FpR(fp_one());
+    fp_batch_inv(x);
+    for (int j = 0; j < CHUNK; ++j) if (first + j < n) raw_fp_store(raw + (first + j) * RAW_FP_STRIDE, x[j]);
+  }
+}
+
+// The staged final exponentiation (fexp_stages.cuh) as the GPU runs it: norm pass, then six stages with a simultaneous
+// inversion before each; every stage runs over the whole batch before the next one starts, all state in scratch.
+static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n) {
+  uint32_t* raw = (uint32_t*)calloc(n ? n : 1, RAW_FP_STRIDE * sizeof(uint32_t));
+  uint32_t* scratch = (uint32_t*)calloc((n ? n : 1) * (size_t)FX_DWORDS_PER_LANE, sizeof(uint32_t));
+  if (!raw || !scratch) return 2;
+  auto sc = [&](size_t i) { return FexpScratch{LaneScratch{scratch, n, i}, raw, i}; };
+  for (size_t i = 0; i < n; ++i) raw_fp_store(raw + i * RAW_FP_STRIDE, fp12_inv_norm_call(fp12_load(a + 72 * i, form)));
+  batch_inv_raw(raw, n);
+  for (size_t i = 0; i < n; ++i) fexp_stage1(fp12_load(a + 72 * i, form), sc(i));
+  batch_inv_raw(raw, n);
+  for (size_t i = 0; i < n; ++i) fexp_stage2(sc(i));
+  batch_inv_raw(raw, n);
+  for (size_t i = 0; i < n; ++i) fexp_stage3(sc(i));
+  batch_inv_raw(raw, n);
+  for (size_t i = 0; i < n; ++i) fexp_stage4(sc(i));
+  batch_inv_raw(raw, n);
+  for (size_t i = 0; i < n; ++i) fexp_stage5(sc(i));
+  batch_inv_raw(raw, n);
+  for (size_t i = 0; i < n; ++i) fp12_store(out + 72 * i, fexp_stage6(sc(i)), form);
+  free(raw); free(scratch);
+  return 0;
+}
+
 int hostsim_fp12_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   if (op == OP12_FINAL_EXP_SPLIT) return final_exp_split(form, a, out, n);
+  if (op == 9) return final_exp_staged(form, a, out, n);
   for (size_t i = 0; i < n; ++i) {
     Fp12R x = fp12_load(a + 72 * i, form);
     Fp12R y = b ? fp12_load(b + 72 * i, form) : x;

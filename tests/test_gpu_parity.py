@@ -58,37 +58,48 @@ def test_tower_ops_golden(engine):
     assert dec_fp12s(engine.fp12_op(B.FP12_CYCLOTOMIC_EXP, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
 
 
-def test_final_exp_batched_inversion_matches_self_contained(engine):
-    """BLS381_OPT_FEXP_BATCHED_INVERSION: the split final exponentiation (norm kernel, simultaneous inversion eight per
-    lane, finishing kernel) and the self-contained kernel give the oracle's bits, for ragged batch sizes (chunk tails,
-    context scratch growing between calls) and with zero elements inside a chunk (zero stays zero, neighbours intact)."""
+def test_final_exp_modes_agree_with_the_oracle(engine):
+    """BLS381_OPT_FEXP_MODE: the self-contained kernel, the split form (norm kernel, simultaneous inversion eight per lane,
+    finishing kernel) and the staged form (Karabina-compressed squaring chains, six stages) give the oracle's bits, for
+    ragged batch sizes (chunk tails, context scratch growing between calls), with zero elements inside a chunk (zero
+    stays zero, neighbours intact) and with the identity (all-zero compressed form: the zero-denominator path)."""
     rng = random.Random(401)
     vals = [rand_fp12(rng) for _ in range(21)]
     zero = O.fp12_unflatten([0] * 12)
     vals[3] = zero; vals[16] = zero
+    vals[5] = O.fp12_unflatten([1] + [0] * 11)
     exp = [O.final_exponentiation(v) or zero for v in vals]
     X = enc_fp12s(vals)
-    assert engine.get_option(B.OPT_FEXP_BATCHED_INVERSION) == 1            # default
+    default = engine.get_option(B.OPT_FEXP_MODE)
+    assert default in (B.FEXP_BATCHED_INVERSION, B.FEXP_STAGED)
     try:
-        for batched in (1, 0):
-            engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, batched)
+        for mode in (B.FEXP_STAGED, B.FEXP_BATCHED_INVERSION, B.FEXP_SELF_CONTAINED):
+            engine.set_option(B.OPT_FEXP_MODE, mode)
             for n in (1, 7, 8, 9, 21):
-                assert dec_fp12s(engine.final_exponentiation(X[: 72 * n])) == exp[:n], (batched, n)
+                assert dec_fp12s(engine.final_exponentiation(X[: 72 * n])) == exp[:n], (mode, n)
+        with pytest.raises(B.Bls381Error):
+            engine.set_option(B.OPT_FEXP_MODE, 3)
     finally:
-        engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, 1)
+        engine.set_option(B.OPT_FEXP_MODE, default)
 
 
-def test_pairing_same_bits_with_and_without_batched_inversion(engine, coracle):
+def test_pairing_same_bits_in_every_fexp_mode(engine, coracle):
     n = 300                                                               # not a multiple of the chunk or the wave
     g1, g2 = synthetic_batch(n, jacobian=False, pool=16)
     exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
+    default = engine.get_option(B.OPT_FEXP_MODE)
     try:
-        for batched in (1, 0):
-            engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, batched)
+        for mode in (B.FEXP_STAGED, B.FEXP_BATCHED_INVERSION, B.FEXP_SELF_CONTAINED):
+            engine.set_option(B.OPT_FEXP_MODE, mode)
             out, fl = engine.multi_pairing(g1, g2, 1)
-            assert np.array_equal(out, exp) and np.array_equal(fl, efl), batched
+            assert np.array_equal(out, exp) and np.array_equal(fl, efl), mode
+            for blk in (128, 256):                                        # the lane-sliced scratch follows the launch shape
+                engine.set_option(B.OPT_BLOCK_SIZE, blk)
+                out, fl = engine.multi_pairing(g1, g2, 1)
+                assert np.array_equal(out, exp), (mode, blk)
+            engine.set_option(B.OPT_BLOCK_SIZE, 64)
     finally:
-        engine.set_option(B.OPT_FEXP_BATCHED_INVERSION, 1)
+        engine.set_option(B.OPT_FEXP_MODE, default); engine.set_option(B.OPT_BLOCK_SIZE, 64)
 
 
 def test_point_surface_g1_g2(engine):

@@ -77,6 +77,26 @@ def test_final_exp_split_with_batched_inversion(hostsim):
         assert dec_fp12s(hostsim.fp12_op(8, X[:72 * n])) == exp[:n], n
 
 
+def test_final_exp_staged_with_compressed_squarings(hostsim):
+    """The six-stage final exponentiation (Karabina-compressed squaring chains, their decompression denominators inverted
+    batch-wide between the stages; csrc/fexp_stages.cuh) gives the oracle's bits: random Fq12 inputs, the identity (whose
+    compressed form is all zero: the zero-denominator path), an element of GT, and a zero input (stays zero)."""
+    rng = random.Random(78)
+    vals = [rand_fp12(rng) for _ in range(10)]
+    zero = O.fp12_unflatten([0] * 12)
+    vals[1] = O.fp12_unflatten([1] + [0] * 11)          # one
+    vals[4] = zero
+    from blsutil import point_pool
+    p1, p2 = point_pool(4)
+    vals[6] = O.miller_loop(p1[1], p2[2])               # a genuine Miller value
+    vals[7] = O.pairing(p1[0], p2[0])                   # already in GT
+    X = enc_fp12s(vals)
+    exp = [O.final_exponentiation(v) or zero for v in vals]
+    assert dec_fp12s(hostsim.fp12_op(9, X)) == exp
+    for n in (1, 3):
+        assert dec_fp12s(hostsim.fp12_op(9, X[:72 * n])) == exp[:n], n
+
+
 def test_mode_a_golden_both_variants(hostsim):
     cases = load_golden("mode_a.json")["cases"]
     g1 = enc_fps([v for c in cases for v in hx(c["g1_jac"])])
