@@ -93,7 +93,7 @@ def main():
         eng.set_option(B.OPT_FEXP_MODE, args.fexp_mode)
     fexp_mode = eng.get_option(B.OPT_FEXP_MODE)
     fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
-                    "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>)")[fexp_mode]
+                    "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>), two half-batch pipelines")[fexp_mode]
 
     g16 = args.workload in ("groth16", "groth16_prepared")
     k = 3 if g16 else 1

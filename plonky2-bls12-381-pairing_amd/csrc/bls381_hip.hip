@@ -174,23 +174,32 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   *plan = FexpPlan();
   if (c->fexp_mode == BLS381_FEXP_SELF_CONTAINED) return BLS381_OK;
   if (c->scratch_used && c->scratch_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->scratch_done, 0));
-  const size_t chunk = (c->fexp_mode == BLS381_FEXP_STAGED && n > FEXP_CHUNK) ? FEXP_CHUNK : n;
-  const size_t stage_bytes = (c->fexp_mode == BLS381_FEXP_STAGED) ? bls_launch::fexp_stage_scratch_bytes(chunk) : 0;
-  if (c->raw_scratch_elems < chunk || c->stage_scratch_bytes < stage_bytes) {
+  bool staged = c->fexp_mode == BLS381_FEXP_STAGED;
+  // raw scratch always covers the whole batch (the batched-inversion form, also the fallback, is not chunked)
+  const size_t chunk = (staged && n > FEXP_CHUNK) ? FEXP_CHUNK : n;
+  const size_t stage_bytes = staged ? bls_launch::fexp_stage_scratch_bytes(chunk) : 0;
+  if (c->raw_scratch_elems < n || c->stage_scratch_bytes < stage_bytes) {
     if (c->scratch_used) HIP_TRY(c, hipEventSynchronize(c->scratch_done));
-    if (c->raw_scratch_elems < chunk) {
+    if (c->raw_scratch_elems < n) {
       if (c->raw_scratch) { (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0; }
-      HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, chunk * 16 * sizeof(uint32_t)));
-      c->raw_scratch_elems = chunk;
+      HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, n * 16 * sizeof(uint32_t)));
+      c->raw_scratch_elems = n;
     }
     if (c->stage_scratch_bytes < stage_bytes) {
       if (c->stage_scratch) { (void)hipFree(c->stage_scratch); c->stage_scratch = nullptr; c->stage_scratch_bytes = 0; }
-      HIP_TRY(c, hipMalloc((void**)&c->stage_scratch, stage_bytes));
-      c->stage_scratch_bytes = stage_bytes;
+      const hipError_t e = hipMalloc((void**)&c->stage_scratch, stage_bytes);
+      if (e == hipErrorOutOfMemory) {            // no room for the stage scratch: this call runs the batched-inversion form
+        (void)hipGetLastError();
+        c->stage_scratch = nullptr;
+        staged = false;
+      } else {
+        HIP_TRY(c, e);
+        c->stage_scratch_bytes = stage_bytes;
+      }
     }
   }
   plan->raw = c->raw_scratch;
-  plan->stage = (c->fexp_mode == BLS381_FEXP_STAGED) ? c->stage_scratch : nullptr;
+  plan->stage = staged ? c->stage_scratch : nullptr;
   plan->chunk = chunk;
   return BLS381_OK;
 }

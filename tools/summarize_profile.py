@@ -12,20 +12,39 @@ dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
 # one bench step = one launch of each ("k_final_exp" also matches k_final_exp_given; only one of the two runs)
-KERNELS = ("k_multi_miller", "k_fexp_norm", "k_fp_batch_inv", "k_final_exp")
+KERNELS = ("k_multi_miller", "k_fexp_norm", "k_fp_batch_inv", "k_final_exp", "k_fexp_stage")
 
 
 def counters(path):
-    """per-step counter totals: mean over dispatches of each kernel, summed over the kernels of a step"""
-    per = {}
+    """per-step counter totals: all dispatches of the step's kernels summed, divided by the number of steps (= launches
+    of the Miller kernel; the staged final exponentiation launches each of its kernels several times per step)"""
+    tot, steps = {}, set()
     for r in csv.DictReader(open(path)):
-        for kn in KERNELS:
-            if kn in r["Kernel_Name"]:
-                per.setdefault((kn, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
-    out = {}
-    for (kn, c), v in per.items():
-        out[c] = out.get(c, 0.0) + sum(v) / len(v)
-    return out
+        if not any(kn in r["Kernel_Name"] for kn in KERNELS):
+            continue
+        tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        if "k_multi_miller" in r["Kernel_Name"]:
+            steps.add(r["Dispatch_Id"])
+    n = max(1, len(steps))
+    return {c: v / n for c, v in tot.items()}
+
+
+def step_walls(trace_path):
+    """wall time of each bench step from the kernel trace: Miller kernel start to the end of the last kernel before the
+    next Miller kernel (kernels of the two final-exponentiation pipelines overlap, so durations do not add up)"""
+    rows = [r for r in csv.DictReader(open(trace_path)) if any(kn in r["Kernel_Name"] for kn in KERNELS)]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    walls, start, end = [], None, None
+    for r in rows:
+        if "k_multi_miller" in r["Kernel_Name"]:
+            if start is not None:
+                walls.append((end - start) / 1e6)
+            start, end = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        elif start is not None:
+            end = max(end, int(r["End_Timestamp"]))
+    if start is not None:
+        walls.append((end - start) / 1e6)
+    return walls
 
 for sub, name in (("stats/s_kernel_stats.csv", "kernel_stats.csv"), ("stats/s_kernel_trace.csv", "kernel_trace.csv"),
                   ("fetch/c_counter_collection.csv", "pmc_fetch_size.csv"), ("write/c_counter_collection.csv", "pmc_write_size.csv"),
@@ -41,7 +60,8 @@ stats = list(csv.DictReader(open(os.path.join(src, "stats/s_kernel_stats.csv")))
 ks = [r for r in stats if any(kn in r["Name"] for kn in KERNELS)]
 summary = {
     "tag": tag, "kernels": {r["Name"].split("(")[0]: {"avg_ms": float(r["AverageNs"]) / 1e6, "calls": int(r["Calls"])} for r in ks},
-    "rocprof_avg_ms": sum(float(r["AverageNs"]) for r in ks) / 1e6,
+    "rocprof_step_wall_ms": step_walls(os.path.join(src, "stats/s_kernel_trace.csv")),
+    "rocprof_busy_ms_per_step": sum(float(r["TotalDurationNs"]) for r in ks) / 1e6 / max(1, max(int(r["Calls"]) for r in ks if "k_multi_miller" in r["Name"])),
     "fetch_size_kib": fetch, "write_size_kib": write,
     "hbm_read_bytes_raw": fetch * 1024, "hbm_read_bytes_corrected_x2": 2 * fetch * 1024, "hbm_write_bytes": write * 1024,
     "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
