@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fexp-pipelines", type=int, default=0, help="BLS381_OPT_FEXP_PIPELINES (1..4; 0 = library default)")
     ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2], default=-1,
                     help="BLS381_OPT_FEXP_MODE: 0 self-contained kernel, 1 batched inversion, 2 staged (compressed squarings); -1 = library default")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
@@ -91,6 +92,8 @@ def main():
         eng.set_option(B.OPT_BLOCK_SIZE, args.block)
     if args.fexp_mode >= 0:
         eng.set_option(B.OPT_FEXP_MODE, args.fexp_mode)
+    if args.fexp_pipelines:
+        eng.set_option(B.OPT_FEXP_PIPELINES, args.fexp_pipelines)
     fexp_mode = eng.get_option(B.OPT_FEXP_MODE)
     fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
                     "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>), two half-batch pipelines")[fexp_mode]

@@ -30,8 +30,10 @@ struct bls381_ctx {
   hipEvent_t scratch_done = nullptr; // recorded after the last launch that used raw_scratch
   // staged final exponentiation: the batch runs as two half-batch pipelines on two auxiliary streams, so that the ramp,
   // tail and stalls of one stage kernel (and the latency-bound inversion kernels) overlap with the other half's work
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t fork = nullptr, stagger = nullptr, join[2] = {nullptr, nullptr};
+  static constexpr int MAX_PIPES = 4;
+  int pipes = 2;                     // BLS381_OPT_FEXP_PIPELINES
+  hipStream_t aux[MAX_PIPES] = {};
+  hipEvent_t fork = nullptr, stagger[MAX_PIPES] = {}, join[MAX_PIPES] = {};
   hipStream_t scratch_stream = nullptr;
   bool scratch_used = false;
 };
@@ -67,12 +69,14 @@ int bls381_create(bls381_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->aux[0], hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->stagger, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->join[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->join[1], hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) {
+    bls381_destroy(c);
+    return BLS381_E_NO_DEVICE;
+  }
+  for (int i = 0; i < bls381_ctx::MAX_PIPES; ++i) {
+    if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&c->stagger[i], hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming) == hipSuccess) continue;
     bls381_destroy(c);
     return BLS381_E_NO_DEVICE;
   }
@@ -90,12 +94,12 @@ void bls381_destroy(bls381_ctx* c) {
   if (c->raw_scratch) (void)hipFree(c->raw_scratch);
   if (c->stage_scratch) (void)hipFree(c->stage_scratch);
   if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < bls381_ctx::MAX_PIPES; ++i) {
     if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+    if (c->stagger[i]) (void)hipEventDestroy(c->stagger[i]);
   }
   if (c->fork) (void)hipEventDestroy(c->fork);
-  if (c->stagger) (void)hipEventDestroy(c->stagger);
   delete c;
 }
 
@@ -112,6 +116,9 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
     case BLS381_OPT_FEXP_MODE:
       if (value < BLS381_FEXP_SELF_CONTAINED || value > BLS381_FEXP_STAGED) return BLS381_E_INVALID;
       c->fexp_mode = value; return BLS381_OK;
+    case BLS381_OPT_FEXP_PIPELINES:
+      if (value < 1 || value > bls381_ctx::MAX_PIPES) return BLS381_E_INVALID;
+      c->pipes = value; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -123,6 +130,7 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_REF_OPT_FP2_SHORTCUT: *value = c->fp2_shortcut; return BLS381_OK;
     case BLS381_OPT_BLOCK_SIZE: *value = c->block; return BLS381_OK;
     case BLS381_OPT_FEXP_MODE: *value = c->fexp_mode; return BLS381_OK;
+    case BLS381_OPT_FEXP_PIPELINES: *value = c->pipes; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -169,6 +177,8 @@ constexpr size_t FEXP_CHUNK = (size_t)1 << 20;      // staged form: elements per
 constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14; // staged form: from this many elements on, two half-batch pipelines
 
 struct FexpPlan { uint32_t* raw = nullptr; uint32_t* stage = nullptr; size_t chunk = 0; };
+// elements per pipeline and pass: an even share of the chunk, rounded up to a multiple of 128
+size_t fexp_part(size_t chunk, int pipes) { return ((chunk + pipes - 1) / pipes + 127) / 128 * 128; }
 
 int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   *plan = FexpPlan();
@@ -177,13 +187,15 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   bool staged = c->fexp_mode == BLS381_FEXP_STAGED;
   // raw scratch always covers the whole batch (the batched-inversion form, also the fallback, is not chunked)
   const size_t chunk = (staged && n > FEXP_CHUNK) ? FEXP_CHUNK : n;
-  const size_t stage_bytes = staged ? bls_launch::fexp_stage_scratch_bytes(chunk) : 0;
-  if (c->raw_scratch_elems < n || c->stage_scratch_bytes < stage_bytes) {
+  // staged: every pipeline owns a share of fexp_part(chunk) elements of both scratches
+  const size_t stage_bytes = staged ? (size_t)c->pipes * bls_launch::fexp_stage_scratch_bytes(fexp_part(chunk, c->pipes)) : 0;
+  const size_t raw_elems = staged ? (n > (size_t)c->pipes * fexp_part(chunk, c->pipes) ? n : (size_t)c->pipes * fexp_part(chunk, c->pipes)) : n;
+  if (c->raw_scratch_elems < raw_elems || c->stage_scratch_bytes < stage_bytes) {
     if (c->scratch_used) HIP_TRY(c, hipEventSynchronize(c->scratch_done));
-    if (c->raw_scratch_elems < n) {
+    if (c->raw_scratch_elems < raw_elems) {
       if (c->raw_scratch) { (void)hipFree(c->raw_scratch); c->raw_scratch = nullptr; c->raw_scratch_elems = 0; }
-      HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, n * 16 * sizeof(uint32_t)));
-      c->raw_scratch_elems = n;
+      HIP_TRY(c, hipMalloc((void**)&c->raw_scratch, raw_elems * 16 * sizeof(uint32_t)));
+      c->raw_scratch_elems = raw_elems;
     }
     if (c->stage_scratch_bytes < stage_bytes) {
       if (c->stage_scratch) { (void)hipFree(c->stage_scratch); c->stage_scratch = nullptr; c->stage_scratch_bytes = 0; }
@@ -205,21 +217,24 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
 }
 // the final exponentiation of `n` elements in the context's mode, queued on c->stream (in place allowed)
 int fexp_launch(bls381_ctx* c, const FexpPlan& plan, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
-  if (plan.stage && n >= FEXP_PIPELINE_MIN) {
-    // two half-batch pipelines: fork from the caller's stream, each half on its own stream and its own half of the
-    // scratch, join back.  Halves are cut at a multiple of 128 elements so that every launch shape fits its scratch half.
-    const size_t half_chunk = plan.chunk / 2 / 128 * 128;
-    const size_t n0 = (n / 2 + 127) / 128 * 128 < n ? (n / 2 + 127) / 128 * 128 : n;
-    const size_t stage_dwords_half = bls_launch::fexp_stage_scratch_bytes(half_chunk) / sizeof(uint32_t);
+  if (plan.stage && n >= FEXP_PIPELINE_MIN && c->pipes > 1) {
+    // `pipes` part-batch pipelines: fork from the caller's stream, each part on its own stream and its own share of the
+    // scratch, join back.  Parts are cut at multiples of 128 elements so that every launch shape fits its scratch share.
+    // Pipeline p starts when pipeline p-1 has its stage 1 through: from then on they are a beat apart, and each one's
+    // inversion kernels, ramps and tails fall into the others' stage kernels.
+    const int P = c->pipes;
+    const size_t part_chunk = fexp_part(plan.chunk, P);           // elements per pipeline and pass (scratch share)
+    const size_t part = fexp_part(n, P);                          // elements per pipeline overall
+    const size_t stage_dwords_part = bls_launch::fexp_stage_scratch_bytes(part_chunk) / sizeof(uint32_t);
     HIP_TRY(c, hipEventRecord(c->fork, c->stream));
-    for (int h = 0; h < 2; ++h) {
-      const size_t first = h ? n0 : 0, cnt = h ? n - n0 : n0;
-      // the second half starts when the first half's stage 1 is through: from then on the two pipelines are half a
-      // beat apart, and each one's inversion kernels, ramps and tails fall into the other's stage kernels
-      HIP_TRY(c, hipStreamWaitEvent(c->aux[h], h ? c->stagger : c->fork, 0));
+    for (int h = 0; h < P; ++h) {
+      const size_t first = (size_t)h * part < n ? (size_t)h * part : n;
+      const size_t cnt = (h == P - 1) ? n - first : (first + part < n ? part : n - first);
+      HIP_TRY(c, hipStreamWaitEvent(c->aux[h], h ? c->stagger[h - 1] : c->fork, 0));
       if (cnt) bls_launch::final_exp_staged(in + 72 * first, out + 72 * first, flags ? flags + first : nullptr, cnt, c->io_form, c->block,
-                                            c->aux[h], plan.raw + (size_t)h * half_chunk * 16, plan.stage + (size_t)h * stage_dwords_half, half_chunk,
-                                            h ? nullptr : c->stagger);
+                                            c->aux[h], plan.raw + (size_t)h * part_chunk * 16, plan.stage + (size_t)h * stage_dwords_part, part_chunk,
+                                            c->stagger[h]);
+      else HIP_TRY(c, hipEventRecord(c->stagger[h], c->aux[h]));
       HIP_TRY(c, hipEventRecord(c->join[h], c->aux[h]));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join[h], 0));
     }

@@ -102,6 +102,23 @@ def test_pairing_same_bits_in_every_fexp_mode(engine, coracle):
         engine.set_option(B.OPT_FEXP_MODE, default); engine.set_option(B.OPT_BLOCK_SIZE, 64)
 
 
+@pytest.mark.parametrize("pipes", [1, 2, 3, 4])
+def test_staged_fexp_pipelines(engine, coracle, pipes):
+    """Staged final exponentiation as 1..4 part-batch pipelines on the context's internal streams (fork/join around the
+    caller's stream, one share of the scratch each): a ragged batch just above the pipelining threshold, against the oracle."""
+    n = (1 << 14) + 77
+    g1, g2 = synthetic_batch(n, seed=600 + pipes, jacobian=False, pool=64)
+    exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
+    default = engine.get_option(B.OPT_FEXP_PIPELINES)
+    try:
+        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_STAGED)
+        engine.set_option(B.OPT_FEXP_PIPELINES, pipes)
+        out, fl = engine.multi_pairing(g1, g2, 1)
+        assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+    finally:
+        engine.set_option(B.OPT_FEXP_PIPELINES, default)
+
+
 def test_point_surface_g1_g2(engine):
     """bls381_g1_op_batch / bls381_g2_op_batch against the oracle (same cases as the host simulation): the arkworks group
     law of opt.rs:93,98 with its fallbacks, normalisation, equality across representatives, curve membership."""
