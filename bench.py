@@ -53,8 +53,9 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fexp-pipelines", type=int, default=0, help="BLS381_OPT_FEXP_PIPELINES (1..4; 0 = library default)")
-    ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2], default=-1,
-                    help="BLS381_OPT_FEXP_MODE: 0 self-contained kernel, 1 batched inversion, 2 staged (compressed squarings); -1 = library default")
+    ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2, 3], default=-1,
+                    help="BLS381_OPT_FEXP_MODE: 0 self-contained kernel, 1 batched inversion, 2 staged (compressed squarings), "
+                         "3 auto (staged from 2^19 elements); -1 = library default (auto)")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
                     "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
     ap.add_argument("--exchange", action="store_true", help="after the timed region, run the one-rank-owns-the-batch flow once: "
@@ -95,6 +96,8 @@ def main():
     if args.fexp_pipelines:
         eng.set_option(B.OPT_FEXP_PIPELINES, args.fexp_pipelines)
     fexp_mode = eng.get_option(B.OPT_FEXP_MODE)
+    if fexp_mode == B.FEXP_AUTO:
+        fexp_mode = B.FEXP_STAGED if (n // 4 if args.workload in ("groth16", "groth16_prepared") else n) >= (1 << 19) else B.FEXP_BATCHED_INVERSION
     fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
                     "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>), two half-batch pipelines")[fexp_mode]
 

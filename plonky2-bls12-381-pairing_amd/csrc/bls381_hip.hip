@@ -114,7 +114,7 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
       if (value != 64 && value != 128 && value != 256) return BLS381_E_INVALID;
       c->block = value; return BLS381_OK;
     case BLS381_OPT_FEXP_MODE:
-      if (value < BLS381_FEXP_SELF_CONTAINED || value > BLS381_FEXP_STAGED) return BLS381_E_INVALID;
+      if (value < BLS381_FEXP_SELF_CONTAINED || value > BLS381_FEXP_AUTO) return BLS381_E_INVALID;
       c->fexp_mode = value; return BLS381_OK;
     case BLS381_OPT_FEXP_PIPELINES:
       if (value < 1 || value > bls381_ctx::MAX_PIPES) return BLS381_E_INVALID;
@@ -174,6 +174,7 @@ struct Timed {
 // bls381_set_stream the new stream first waits for the event recorded behind the last user; an outgrown buffer is released
 // only after that user has finished.
 constexpr size_t FEXP_CHUNK = (size_t)1 << 20;      // staged form: elements per pass (bounds the stage scratch at ~8.9 GB)
+constexpr size_t FEXP_AUTO_STAGED_MIN = (size_t)1 << 19; // BLS381_FEXP_AUTO: staged form from this batch size on
 constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14; // staged form: from this many elements on, two half-batch pipelines
 
 struct FexpPlan { uint32_t* raw = nullptr; uint32_t* stage = nullptr; size_t chunk = 0; };
@@ -184,7 +185,7 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   *plan = FexpPlan();
   if (c->fexp_mode == BLS381_FEXP_SELF_CONTAINED) return BLS381_OK;
   if (c->scratch_used && c->scratch_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->scratch_done, 0));
-  bool staged = c->fexp_mode == BLS381_FEXP_STAGED;
+  bool staged = c->fexp_mode == BLS381_FEXP_STAGED || (c->fexp_mode == BLS381_FEXP_AUTO && n >= FEXP_AUTO_STAGED_MIN);
   // raw scratch always covers the whole batch (the batched-inversion form, also the fallback, is not chunked)
   const size_t chunk = (staged && n > FEXP_CHUNK) ? FEXP_CHUNK : n;
   // staged: every pipeline owns a share of fexp_part(chunk) elements of both scratches
