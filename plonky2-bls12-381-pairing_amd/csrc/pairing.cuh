@@ -72,9 +72,6 @@ template <int L, int V>
 BLS_HD Fp2R fsqr(const Fp2<L, V>& a) { return sqr(a); }
 
 // ---------------------------------------------------------------------- Jacobian G1 / G2 (field-generic)
-BLS_HD_NOINLINE G2Jac jac_double_call(const G2Jac& p);
-BLS_HD_NOINLINE G1Jac jac_double_call(const G1Jac& p);
-
 // ark-ec 0.4.2 `Projective::double_in_place`, a = 0 (EFD dbl-2009-l) [third party; SURVEY App. A.3]
 template <class F>
 BLS_HD Jac<F> jac_double(const Jac<F>& p) {
@@ -90,6 +87,9 @@ BLS_HD Jac<F> jac_double(const Jac<F>& p) {
   r.y = fit<1, 2>(sub(fmul(E, sub(D, X3)), dbl(dbl(dbl(C)))));
   return r;
 }
+
+BLS_HD_NOINLINE G2Jac jac_double_call(const G2Jac& p) { return jac_double(p); }
+BLS_HD_NOINLINE G1Jac jac_double_call(const G1Jac& p) { return jac_double(p); }
 
 // ark-ec 0.4.2 `impl AddAssign<&Self> for Projective` (EFD add-2007-bl) [third party; SURVEY App. A.3]
 template <class F>
@@ -112,8 +112,6 @@ BLS_HD Jac<F> jac_add(const Jac<F>& p1, const Jac<F>& p2) {
   o.z = fit<1, 2>(fmul(sub(sub(fsqr(add(p1.z, p2.z)), Z1Z1), Z2Z2), H));
   return o;
 }
-BLS_HD_NOINLINE G2Jac jac_double_call(const G2Jac& p) { return jac_double(p); }
-BLS_HD_NOINLINE G1Jac jac_double_call(const G1Jac& p) { return jac_double(p); }
 BLS_HD G2Jac g2_jac_double(const G2Jac& p) { return jac_double_call(p); }
 BLS_HD_NOINLINE G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) { return jac_add(p1, p2); }
 

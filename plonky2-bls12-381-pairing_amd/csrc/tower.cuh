@@ -263,7 +263,6 @@ BLS_FN_FP12 Fp12R mul_by_014(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const F
 BLS_HD_NOINLINE Fp12R mul_call(const Fp12R& a, const Fp12R& b) { return mul(a, b); }
 BLS_HD_NOINLINE Fp12R sqr_call(const Fp12R& a) { return sqr(a); }
 BLS_HD_NOINLINE Fp12R frobenius_call(const Fp12R& a) { return frobenius(a); }
-BLS_HD_NOINLINE Fp12R cyclotomic_square_call(const Fp12R& a);
 
 // ---- cyclotomic subgroup (final exponentiation)   -- src/fields_as_trees/miller_loop.rs:29-126
 template <class A, class B> struct Pair2 { A a; B b; };
