@@ -231,16 +231,17 @@ int fexp_launch(bls381_ctx* c, const FexpPlan& plan, const uint64_t* in, uint64_
     for (int h = 0; h < P; ++h) {
       const size_t first = (size_t)h * part < n ? (size_t)h * part : n;
       const size_t cnt = (h == P - 1) ? n - first : (first + part < n ? part : n - first);
+      hipEvent_t record_after[6] = {c->stagger[h]};                // behind this pipeline's stage 1
       HIP_TRY(c, hipStreamWaitEvent(c->aux[h], h ? c->stagger[h - 1] : c->fork, 0));
       if (cnt) bls_launch::final_exp_staged(in + 72 * first, out + 72 * first, flags ? flags + first : nullptr, cnt, c->io_form, c->block,
                                             c->aux[h], plan.raw + (size_t)h * part_chunk * 16, plan.stage + (size_t)h * stage_dwords_part, part_chunk,
-                                            c->stagger[h]);
+                                            nullptr, record_after);
       else HIP_TRY(c, hipEventRecord(c->stagger[h], c->aux[h]));
       HIP_TRY(c, hipEventRecord(c->join[h], c->aux[h]));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join[h], 0));
     }
   } else if (plan.stage) {
-    bls_launch::final_exp_staged(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw, plan.stage, plan.chunk, nullptr);
+    bls_launch::final_exp_staged(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw, plan.stage, plan.chunk, nullptr, nullptr);
   } else {
     bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw);
   }

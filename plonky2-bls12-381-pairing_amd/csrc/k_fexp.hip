@@ -79,7 +79,8 @@ size_t fexp_stage_scratch_bytes(size_t n_chunk) {      // for a chunk of n_chunk
 // Staged final exponentiation over chunks of at most `chunk` elements; raw_scratch: chunk x RAW_FP_STRIDE dwords,
 // stage_scratch: fexp_stage_scratch_bytes(chunk)
 void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
-                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk, hipEvent_t after_first_stage) {
+                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
+                      const hipEvent_t* wait_before, const hipEvent_t* record_after) {
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first < chunk) ? n - first : chunk;
     const dim3 grid(grid_for(m, block)), blk(block);
@@ -87,20 +88,34 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
     const uint64_t* ci = in + 72 * first;
     uint64_t* co = out + 72 * first;
     uint8_t* cf = flags ? flags + first : nullptr;
+    // events tie the stage kernels of the first pass to another pipeline's (see bls381_hip.hip)
+    auto before = [&](int k) { if (first == 0 && wait_before && wait_before[k]) (void)hipStreamWaitEvent(s, wait_before[k], 0); };
+    auto after = [&](int k) { if (first == 0 && record_after && record_after[k]) (void)hipEventRecord(record_after[k], s); };
     hipLaunchKernelGGL(k_fexp_norm, grid, blk, 0, s, ci, raw_scratch, m, form);
     fp_batch_inv_raw(raw_scratch, m, s);
+    before(0);
     hipLaunchKernelGGL(k_fexp_stage<1>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
-    if (after_first_stage && first == 0) (void)hipEventRecord(after_first_stage, s);
+    after(0);
     fp_batch_inv_raw(raw_scratch, m, s);
+    before(1);
     hipLaunchKernelGGL(k_fexp_stage<2>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    after(1);
     fp_batch_inv_raw(raw_scratch, m, s);
+    before(2);
     hipLaunchKernelGGL(k_fexp_stage<3>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    after(2);
     fp_batch_inv_raw(raw_scratch, m, s);
+    before(3);
     hipLaunchKernelGGL(k_fexp_stage<4>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    after(3);
     fp_batch_inv_raw(raw_scratch, m, s);
+    before(4);
     hipLaunchKernelGGL(k_fexp_stage<5>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    after(4);
     fp_batch_inv_raw(raw_scratch, m, s);
+    before(5);
     hipLaunchKernelGGL(k_fexp_stage<6>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    after(5);
   }
 }
 // `raw_scratch`: n x RAW_FP_STRIDE dwords of device memory for the split form, or nullptr for the self-contained kernel

@@ -16,11 +16,12 @@ void multi_k4(const uint64_t*, const uint64_t*, uint64_t*, uint8_t*, size_t, int
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);
 void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s);
 // staged form (Karabina-compressed squaring chains, csrc/fexp_stages.cuh): processes the batch in chunks of `chunk` elements;
-// raw_scratch: chunk x 16 dwords, stage_scratch: fexp_stage_scratch_bytes(chunk) bytes; `after_first_stage` (optional) is
-// recorded behind the first stage-1 launch so that a second pipeline can start half a beat later
+// raw_scratch: chunk x 16 dwords, stage_scratch: fexp_stage_scratch_bytes(chunk) bytes; wait_before[k] / record_after[k]
+// (arrays of six, entries or the arrays may be null) are waited for before / recorded behind stage kernel k+1 of the first pass
 size_t fexp_stage_scratch_bytes(size_t n_chunk);
 void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
-                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk, hipEvent_t after_first_stage);
+                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
+                      const hipEvent_t* wait_before, const hipEvent_t* record_after);
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp6_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
