@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hom-miller", type=int, choices=[-1, 0, 1], default=-1, help="BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER (-1 = library default)")
     ap.add_argument("--fexp-pipelines", type=int, default=0, help="BLS381_OPT_FEXP_PIPELINES (1..4; 0 = library default)")
     ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2, 3], default=-1,
                     help="BLS381_OPT_FEXP_MODE: 0 self-contained kernel, 1 batched inversion, 2 staged (compressed squarings), "
@@ -95,6 +96,8 @@ def main():
         eng.set_option(B.OPT_FEXP_MODE, args.fexp_mode)
     if args.fexp_pipelines:
         eng.set_option(B.OPT_FEXP_PIPELINES, args.fexp_pipelines)
+    if args.hom_miller >= 0:
+        eng.set_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER, args.hom_miller)
     fexp_mode = eng.get_option(B.OPT_FEXP_MODE)
     if fexp_mode == B.FEXP_AUTO:
         fexp_mode = B.FEXP_STAGED if (n // 4 if args.workload in ("groth16", "groth16_prepared") else n) >= (1 << 19) else B.FEXP_BATCHED_INVERSION

@@ -32,6 +32,7 @@ struct bls381_ctx {
   // tail and stalls of one stage kernel (and the latency-bound inversion kernels) overlap with the other half's work
   static constexpr int MAX_PIPES = 4;
   int pipes = 2;                     // BLS381_OPT_FEXP_PIPELINES
+  int hom_miller = 1;                // BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER
   hipStream_t aux[MAX_PIPES] = {};
   hipEvent_t fork = nullptr, stagger[MAX_PIPES] = {}, join[MAX_PIPES] = {};
   hipStream_t scratch_stream = nullptr;
@@ -119,6 +120,7 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
     case BLS381_OPT_FEXP_PIPELINES:
       if (value < 1 || value > bls381_ctx::MAX_PIPES) return BLS381_E_INVALID;
       c->pipes = value; return BLS381_OK;
+    case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: c->hom_miller = value ? 1 : 0; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -131,6 +133,7 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_BLOCK_SIZE: *value = c->block; return BLS381_OK;
     case BLS381_OPT_FEXP_MODE: *value = c->fexp_mode; return BLS381_OK;
     case BLS381_OPT_FEXP_PIPELINES: *value = c->pipes; return BLS381_OK;
+    case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: *value = c->hom_miller; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -273,7 +276,7 @@ int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k
   int rc = BLS381_OK;
   {
     Timed t(c);
-    if (!bls_launch::multi(k, g1, g2, out, flags, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
+    if (!bls_launch::multi(k, FE && c->hom_miller, g1, g2, out, flags, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
     if (FE) rc = fexp_launch(c, plan, out, out, nullptr, n);
   }
   if (rc != BLS381_OK) return rc;

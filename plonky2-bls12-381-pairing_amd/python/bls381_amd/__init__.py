@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hip.so"))
 
 IO_ARK_MONT, IO_CANONICAL = 0, 1
-OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE, OPT_FEXP_MODE, OPT_FEXP_PIPELINES = 0, 1, 2, 3, 4
+OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE, OPT_FEXP_MODE, OPT_FEXP_PIPELINES, OPT_PAIRING_HOMOGENEOUS_MILLER = 0, 1, 2, 3, 4, 5
 FEXP_SELF_CONTAINED, FEXP_BATCHED_INVERSION, FEXP_STAGED, FEXP_AUTO = 0, 1, 2, 3
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_TRUE = 32

@@ -271,7 +271,8 @@ static void multi_one(int form, int with_final_exp, const uint64_t* g1, const ui
     skip[j] = i1 || i2;
     if (skip[j]) fl |= FLAG_INFINITY;
   }
-  Fp12R f = miller_ate<K>(p, q, skip);
+  // like the GPU: full pairings walk the Miller loop in homogeneous coordinates, Miller-only results keep Alg. 26/27
+  Fp12R f = with_final_exp ? miller_ate<K, true>(p, q, skip) : miller_ate<K, false>(p, q, skip);
   if (with_final_exp) f = final_exponentiation(f);
   fp12_store(out, f, form);
   if (flag) *flag = fl;

@@ -43,7 +43,10 @@ k_pair(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_
   (void)p; (void)q; (void)skip;
   f = final_exponentiation(f);
 #else
-  Fp12R f = miller_ate<1>(p, q, skip);
+#ifndef KB_HOM
+#define KB_HOM false
+#endif
+  Fp12R f = miller_ate<1, KB_HOM>(p, q, skip);
   if (KB_FE) f = final_exponentiation(f);
 #endif
   fp12_store(out + 72 * i, f, 0);
