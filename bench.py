@@ -239,7 +239,7 @@ def main():
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
                          "algorithmic_bytes_per_launch": bytes_per_unit * n_units,
                          "kernel": "k_prepared_miller<1,2> + %s" % fexp_kernels if args.workload == "groth16_prepared" else
-                                   ("k_multi_miller<%d,false> + %s (one step = all of these launches)" % (k, fexp_kernels)) if args.workload in ("pairing", "groth16")
+                                   ("k_multi_miller<%d,%s> + %s (one step = all of these launches)" % (k, "true" if eng.get_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER) and k <= 3 else "false", fexp_kernels)) if args.workload in ("pairing", "groth16")
                                    else ("k_multi_miller<%d,false>" % k if args.workload == "miller" else "k_miller_ref_opt"),
                          "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
                          "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},
