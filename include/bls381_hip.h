@@ -62,7 +62,7 @@ enum {
 enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
        BLS381_OPT_FEXP_MODE = 3 /* how the final exponentiation (src/fields_as_trees/miller_loop.rs:128-178) is run; same output bits */,
        BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams (default 2) */,
-       BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch walks its Miller loop with homogeneous-
+       BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch (k <= 3) walks its Miller loop with homogeneous-
           projective curve steps (3 M + 6 S per doubling instead of Alg. 26's 3 M + 8 S, src/miller_loop_native.rs:27-55); the Miller
           value differs by an Fp2 factor that the final exponentiation kills, the pairing is bit-identical.  Miller-only entry
           points always follow Alg. 26/27. */ };
