@@ -64,8 +64,9 @@ enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_B
        BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams (default 2) */,
        BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch (k <= 3) walks its Miller loop with homogeneous-
           projective curve steps (3 M + 6 S per doubling instead of Alg. 26's 3 M + 8 S, src/miller_loop_native.rs:27-55); the Miller
-          value differs by an Fp2 factor that the final exponentiation kills, the pairing is bit-identical.  Miller-only entry
-          points always follow Alg. 26/27. */ };
+          value differs by an Fp2 factor that the final exponentiation kills, the pairing is bit-identical FOR POINTS ON THE CURVES
+          (what arkworks' affine types hold); for other coordinate values only 0 reproduces the reference's arithmetic.
+          Miller-only entry points always follow Alg. 26/27. */ };
 enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per element */
        BLS381_FEXP_BATCHED_INVERSION = 1, /* the Fp inversion under f^-1 (:175) from a batch-wide simultaneous inversion: three launches,
                                              64 B of context-owned device scratch per element */

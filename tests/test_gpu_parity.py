@@ -119,6 +119,28 @@ def test_staged_fexp_pipelines(engine, coracle, pipes):
         engine.set_option(B.OPT_FEXP_PIPELINES, default)
 
 
+def test_homogeneous_miller_option_domain(engine, coracle):
+    """BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: on curve points the pairing has the same bits either way (the lines differ by
+    Fp2 factors the final exponentiation kills); on inputs that are NOT on the curves only the Alg. 26/27 path is the
+    reference's arithmetic -- documented, and pinned here so that it stays true."""
+    n = 64
+    g1, g2 = synthetic_batch(n, seed=808, jacobian=False, pool=32)
+    exp, _ = coracle.multi(g1, g2, 1, final_exp=True, threads=8)
+    rs = np.random.default_rng(5)
+    a = np.frombuffer(rs.bytes(n * 96), dtype=np.uint64).copy(); a[5::6] &= np.uint64(0x0fffffffffffffff)
+    b = np.frombuffer(rs.bytes(n * 192), dtype=np.uint64).copy(); b[5::6] &= np.uint64(0x0fffffffffffffff)
+    gexp, _ = coracle.multi(a, b, 1, final_exp=True, threads=8)
+    assert engine.get_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER) == 1
+    try:
+        for hom in (1, 0):
+            engine.set_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER, hom)
+            assert np.array_equal(engine.multi_pairing(g1, g2, 1)[0], exp), hom
+        assert np.array_equal(engine.multi_pairing(a, b, 1)[0], gexp)             # Alg. 26/27 on garbage == oracle
+        assert np.array_equal(engine.multi_miller_loop(a, b, 1)[0], coracle.multi(a, b, 1, final_exp=False, threads=8)[0])
+    finally:
+        engine.set_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER, 1)
+
+
 def test_point_surface_g1_g2(engine):
     """bls381_g1_op_batch / bls381_g2_op_batch against the oracle (same cases as the host simulation): the arkworks group
     law of opt.rs:93,98 with its fallbacks, normalisation, equality across representatives, curve membership."""

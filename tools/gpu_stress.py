@@ -33,7 +33,11 @@ for k in (1, 2, 3):
     a = np.frombuffer(np.random.default_rng(seed + 10 + k).bytes(n * k * 96), dtype=np.uint64).copy(); a[5::6] &= np.uint64(0x0fffffffffffffff)
     b = np.frombuffer(np.random.default_rng(seed + 20 + k).bytes(n * k * 192), dtype=np.uint64).copy(); b[5::6] &= np.uint64(0x0fffffffffffffff)
     exp, efl = orc.multi(a, b, k, final_exp=True, threads=16)
+    # off the curve the homogeneous Miller steps and Alg. 26/27 are different functions (their lines are proportional only
+    # through the curve equation): arithmetic parity on garbage is a statement about the Alg. 26/27 path
+    eng.set_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER, 0)
     out, fl = eng.multi_pairing(a, b, k)
+    eng.set_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER, 1)
     assert np.array_equal(out, exp) and np.array_equal(fl, efl), ("pairing garbage", k)
     expm, _ = orc.multi(a, b, k, final_exp=False, threads=16)
     outm, _ = eng.multi_miller_loop(a, b, k)
