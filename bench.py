@@ -1,31 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: BLS12-381 pairings/sec (Miller loop + final exponentiation), batch 2^20 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          # N = 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # N > 1
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One process per GPU.  A step = one pass of the hot path (bls381_multi_pairing_batch_dev, k = 1) over this rank's
-batch of 2^20 synthetic (G1, G2) pairs already resident in HBM; pairings are independent, so ranks share nothing
-on the data path (weak scaling, total batch = N * 2^20 -- BASELINE.json config "2^23 across 8 GPUs").
-Rank 0 prints ONE JSON line.  `roofline` prices the kernel against HBM as BASELINE.json asks (the path is
-integer-ALU bound, so that fraction is tiny by construction; `int_roofline` prices it against the measured
-v_mad_u64_u32 issue rate).  `cpu_baseline` times the C restatement of the same path (oracle/, a port -- the
-Rust reference cannot be built here) on this box's host cores, on a bounded sample.
+One process per GPU.  With --gpus N > 1 and no torch.distributed environment, this process starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`, BEFORE
+any GPU call) and relays rank 0's JSON line and the children's exit status; started under torchrun it is a rank.
+
+A step = one pass of the hot path (bls381_multi_pairing_batch_dev, k = 1) over this rank's batch of 2^20 synthetic
+(G1, G2) pairs already resident in HBM; pairings are independent, so ranks share nothing on the data path (weak scaling,
+total batch = N * 2^20 -- BASELINE.json config "2^23 across 8 GPUs").  Rank 0 prints ONE JSON line.
+
+Inputs: pools of 4096 subgroup points built on the GPU with the library's own
+point kernels; element i pairs P_{i mod 4096} with Q_{(i * 2654435761 >> 12) mod 4096} -- 2^20 distinct pairings per rank.
+
+`roofline` prices the kernel against HBM as BASELINE.json asks (the path is integer-ALU bound, so that fraction is tiny by
+construction; `int_roofline` prices it against the measured v_mad_u64_u32 issue rate).  `cpu_baseline` times the C
+restatement of the same path (oracle/, a port -- the Rust reference cannot be built here) on this box's host cores, on a
+bounded sample.  oracle/ is touched only for that leg and for the parity spot check, both outside the timed region.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "python"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np
-import torch
 
 # algorithmic figures (DESIGN.md "Measurement")
 BYTES_PER_PAIRING = 96 + 192 + 576          # affine G1 + affine G2 in, Fq12 out, each touched once
@@ -33,6 +38,7 @@ FP_MUL_PER_PAIRING = 6916 + 8491            # oracle op count: Miller loop + fin
 MAC_PER_FP_MUL = 288                        # 32x32->64 limb MACs per 381-bit Montgomery multiplication (2 * 12^2)
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s
 INT_MAC_PEAK = 30.3e12                      # measured v_mad_u64_u32 lane-ops/s, profiles/r01_valu_rates_mi355x.txt
+SPOT_CHECK = 256                            # elements of rank 0's batch compared with the oracle (spread over the batch)
 
 
 def baseline_metric():
@@ -43,7 +49,7 @@ def baseline_metric():
         return "BLS12-381 pairings/sec (Miller+final exp), batch=2^20, 1/2/4/8 MI355X"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -51,7 +57,10 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--workload", choices=["pairing", "miller", "ref_opt", "groth16", "groth16_prepared"], default="pairing")
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--pool", type=int, default=4096, help="points per synthetic pool (SURVEY 8d: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-host", action="store_true", help="also time the host-pointer entry point (bls381_multi_pairing_batch: "
+                    "H2D + kernels + D2H as a caller with host buffers sees it) and report it in config.from_host; never `value`")
     ap.add_argument("--hom-miller", type=int, choices=[-1, 0, 1], default=-1, help="BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER (-1 = library default)")
     ap.add_argument("--fexp-pipelines", type=int, default=0, help="BLS381_OPT_FEXP_PIPELINES (1..4; 0 = library default)")
     ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2, 3], default=-1,
@@ -59,17 +68,47 @@ def main():
                          "3 auto (staged from 2^19 elements); -1 = library default (auto)")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
                     "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
-    ap.add_argument("--exchange", action="store_true", help="after the timed region, run the one-rank-owns-the-batch flow once: "
-                    "RCCL scatter of the inputs from rank 0, local launch, gather of the results (config.exchange); untimed by `value`")
+    ap.add_argument("--exchange", type=int, choices=[0, 1], default=-1, help="after the timed region, run the one-rank-owns-the-batch "
+                    "flow once: scatter of the inputs from rank 0, local launch, gather of the results (config.exchange); untimed by "
+                    "`value`.  Default: on for N > 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def self_launch(args, argv):
+    """--gpus N > 1 outside torchrun: start the N ranks as children (no GPU call has happened in this process) and relay."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print("bench.py: the %d-rank run failed (exit %d, %d result lines)" % (args.gpus, proc.returncode, len(lines)), file=sys.stderr)
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
     distributed = world > 1
     ndev = torch.cuda.device_count()
@@ -85,11 +124,14 @@ def main():
             dist.init_process_group(args.backend)
 
     import bls381_amd as B
-    from blsutil import synthetic_batch
+    from bls381_amd import synthetic
 
     n = 1 << args.batch_log2
     eng = B.Engine(dev_index)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # an explicit stream: every launch of a step, the HIP events that time it and the copies of the exchange flow are
+    # ordered on it (torch's default stream is the legacy null stream)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
     if args.block:
         eng.set_option(B.OPT_BLOCK_SIZE, args.block)
     if args.fexp_mode >= 0:
@@ -99,16 +141,21 @@ def main():
     if args.hom_miller >= 0:
         eng.set_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER, args.hom_miller)
     fexp_mode = eng.get_option(B.OPT_FEXP_MODE)
-    if fexp_mode == B.FEXP_AUTO:
-        fexp_mode = B.FEXP_STAGED if (n // 4 if args.workload in ("groth16", "groth16_prepared") else n) >= (1 << 19) else B.FEXP_BATCHED_INVERSION
-    fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
-                    "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>), two half-batch pipelines")[fexp_mode]
-
     g16 = args.workload in ("groth16", "groth16_prepared")
     k = 3 if g16 else 1
     n_units = n // 4 if g16 else n          # 2^18 proofs x 3 pairs (BASELINE config 4)
+    if fexp_mode == B.FEXP_AUTO:
+        fexp_mode = B.FEXP_STAGED if n_units >= (1 << 19) else B.FEXP_BATCHED_INVERSION
+    fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
+                    "k_fexp_norm + 6 x (k_fp_batch_inv + k_fexp_stage<i>), two half-batch pipelines")[fexp_mode]
+
     jac = args.workload == "ref_opt"
-    g1, g2 = synthetic_batch(n_units, seed=0x424C533132333831 + rank, jacobian=jac, k=k, pool=64)
+    pools = synthetic.build_pools(eng, args.pool)                # on the GPU, with the library's point kernels
+    first = rank * n_units                                       # ranks own consecutive element ranges of one global batch
+    if jac:
+        g1, g2 = synthetic.jacobian_batch(eng, pools, n_units, first)
+    else:
+        g1, g2 = synthetic.affine_batch(pools, n_units, k, first)
     dprep = None
     if args.workload == "groth16_prepared":
         # Q1, Q2 fixed for the batch (the verifying key's points): keep Q0 per proof, prepare the other two once
@@ -120,6 +167,7 @@ def main():
     d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
     dout = torch.empty(n_units * 72, dtype=torch.int64, device=dev)
     dfl = torch.empty(n_units, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
 
     def step():
         if args.workload == "groth16_prepared":
@@ -165,14 +213,19 @@ def main():
         del full
 
     exchange = None
-    if args.exchange and distributed and args.workload == "pairing":
+    do_exchange = args.exchange == 1 or (args.exchange == -1 and distributed)
+    if do_exchange and distributed and args.workload == "pairing":
         # SURVEY 8e flow for a caller whose batch lives on rank 0: scatter inputs, launch, gather results (bls381_amd.sharding).
-        # Every range of the full batch repeats rank 0's shard, so rank 0 can check the gathered result against its own.
+        # Rank 0 rebuilds the whole global batch (ranks own consecutive element ranges of it), every rank then checks the
+        # scattered-and-recomputed results against what it computed from its resident shard.
         from bls381_amd.sharding import scatter_batch, gather_results
         host = args.backend != "nccl"                     # gloo rehearsal: point-to-point needs CPU tensors
         xdev = torch.device("cpu") if host else dev
         n_total = n_units * world
-        full_in = [d1.repeat(world).to(xdev), d2.repeat(world).to(xdev)] if rank == 0 else None
+        full_in = None
+        if rank == 0:
+            f1, f2 = synthetic.affine_batch(pools, n_total, 1, 0)
+            full_in = [torch.from_numpy(f1.view(np.int64)).to(xdev), torch.from_numpy(f2.view(np.int64)).to(xdev)]
         torch.cuda.synchronize(); dist.barrier()
         x0 = time.perf_counter()
         a, b = scatter_batch(full_in, [12, 24], n_total, src=0, device=xdev)
@@ -180,31 +233,55 @@ def main():
         x1 = time.perf_counter()
         a, b = a.to(dev), b.to(dev)
         xo = torch.empty(n_units * 72, dtype=torch.int64, device=dev); xf = torch.empty(n_units, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
         eng.multi_pairing_dev(a.data_ptr(), b.data_ptr(), 1, xo.data_ptr(), xf.data_ptr(), n_units)
+        eng.sync()
         torch.cuda.synchronize(); dist.barrier()
         x2 = time.perf_counter()
+        same_local = bool(torch.equal(xo, dout))
         res = gather_results([xo.to(xdev), xf.to(xdev)], [72, 1], n_total, dst=0)
         torch.cuda.synchronize(); dist.barrier()
         x3 = time.perf_counter()
+        ok_t = torch.tensor([1 if same_local else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         if rank == 0:
-            same = all(torch.equal(res[0][r * n_units * 72:(r + 1) * n_units * 72].to(dev), dout) for r in range(world))
+            same = bool(ok_t.item()) and bool(torch.equal(res[0][: n_units * 72].to(dev), dout))
             if not same:
                 raise SystemExit("bench: scattered/gathered results differ from the resident-shard results")
             in_b, out_b = n_total * 288 * (world - 1) / world, n_total * 577 * (world - 1) / world
             exchange = {"scatter_ms": (x1 - x0) * 1e3, "compute_ms": (x2 - x1) * 1e3, "gather_ms": (x3 - x2) * 1e3,
                         "scatter_GBps": in_b / (x1 - x0) / 1e9, "gather_GBps": out_b / (x3 - x2) / 1e9,
-                        "end_to_end_pairings_per_s": n_total / (x3 - x0), "staged_through_host": host}
+                        "end_to_end_pairings_per_s": n_total / (x3 - x0), "staged_through_host": host,
+                        "results_match_resident_shards": same}
         del full_in, res
 
-    # spot parity inside the bench: the first 64 results of this rank against the oracle (checker only)
+    # spot parity inside the bench: SPOT_CHECK elements spread over rank 0's batch against the oracle (checker only)
     ok = None
     if rank == 0 and args.workload == "pairing":
-        from blsutil import COracle
-        exp, _ = COracle().multi(g1[: 64 * 12], g2[: 64 * 24], 1, final_exp=True, threads=8)
-        got = dout[: 64 * 72].cpu().numpy().view(np.uint64)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from coracle import COracle
+        idx = (np.arange(SPOT_CHECK, dtype=np.int64) * (n_units // SPOT_CHECK if n_units >= SPOT_CHECK else 1)) % n_units
+        s1 = np.ascontiguousarray(g1.reshape(n_units, 12)[idx]).reshape(-1)
+        s2 = np.ascontiguousarray(g2.reshape(n_units, 24)[idx]).reshape(-1)
+        exp, _ = COracle().multi(s1, s2, 1, final_exp=True, threads=8)
+        got = dout.view(n_units, 72)[torch.from_numpy(idx).to(dev)].cpu().numpy().view(np.uint64).reshape(-1)
         ok = bool(np.array_equal(got, exp))
         if not ok:
             raise SystemExit("bench: HIP results differ from the oracle -- number would be invalid")
+
+    from_host = None
+    if args.from_host and rank == 0 and args.workload == "pairing":
+        eng.multi_pairing(g1[: 12 * 1024], g2[: 24 * 1024], 1)          # warm the staging buffers
+        hs = []
+        for _ in range(max(2, args.steps)):
+            h0 = time.perf_counter()
+            hout, _ = eng.multi_pairing(g1, g2, 1)
+            hs.append(time.perf_counter() - h0)
+        if not np.array_equal(hout.view(np.int64), dout.cpu().numpy()):
+            raise SystemExit("bench: host-pointer results differ from the device-pointer results")
+        best = min(hs)
+        from_host = {"ms_per_step": best * 1e3, "pairings_per_s": n_units / best, "vs_resident": (elapsed / args.steps) / best,
+                     "note": "bls381_multi_pairing_batch with pageable numpy buffers: H2D, kernels and D2H included"}
 
     # HBM traffic per launch from the last committed PMC passes (tools/collect_profile.sh + summarize_profile.py):
     # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, read side x2 (gfx950).
@@ -224,6 +301,7 @@ def main():
         if jac:
             bytes_per_unit = 144 + 288 + 576
         achieved_gbs = bytes_per_unit * n_units / avg_kernel_s / 1e9
+        hom = bool(eng.get_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER))
         line = {
             "metric": baseline_metric() if args.workload == "pairing" else "BLS12-381 %s units/sec" % args.workload,
             "value": value, "unit": "pairings/s" if k == 1 else "proofs/s",
@@ -232,14 +310,18 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "batch 2^%d full pairings (Miller loop + Fp12 final exponentiation), 1xMI355X per rank"
                                    % args.batch_log2 if args.workload == "pairing" else args.workload,
-                       "batch_per_gpu": n_units, "pairs_per_unit": k, "io": "arkworks Montgomery 6xu64 AoS, resident in HBM",
-                       "parity_spot_check": ok, "gather_ms": gather_ms, "exchange": exchange},
+                       "batch_per_gpu": n_units, "global_batch": n_units * world, "pairs_per_unit": k,
+                       "inputs": "pools of %d subgroup points built on the GPU; element i = (P[i mod %d], Q[(i*2654435761>>12) mod %d])%s"
+                                 % (args.pool, args.pool, args.pool, ", per-element random Jacobian representative" if jac else ""),
+                       "io": "arkworks Montgomery 6xu64 AoS, resident in HBM",
+                       "parity_spot_check": ok, "parity_spot_check_elements": SPOT_CHECK if ok is not None else 0,
+                       "gather_ms": gather_ms, "exchange": exchange, "from_host": from_host},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/latest_traffic.json)",
                          "algorithmic_bytes_per_launch": bytes_per_unit * n_units,
                          "kernel": "k_prepared_miller<1,2> + %s" % fexp_kernels if args.workload == "groth16_prepared" else
-                                   ("k_multi_miller<%d,%s> + %s (one step = all of these launches)" % (k, "true" if eng.get_option(B.OPT_PAIRING_HOMOGENEOUS_MILLER) and k <= 3 else "false", fexp_kernels)) if args.workload in ("pairing", "groth16")
+                                   ("k_multi_miller<%d,%s> + %s (one step = all of these launches)" % (k, "true" if hom else "false", fexp_kernels)) if args.workload in ("pairing", "groth16")
                                    else ("k_multi_miller<%d,false>" % k if args.workload == "miller" else "k_miller_ref_opt"),
                          "kernel_ms_avg": avg_kernel_s * 1e3, "bytes_per_unit": bytes_per_unit,
                          "note": "integer-ALU bound path: HBM fraction is tiny by construction, see int_roofline"},
@@ -250,17 +332,20 @@ def main():
                                     "unit": "T limb-MAC/s", "frac": macs / INT_MAC_PEAK,
                                     "fp_mul_per_pairing": FP_MUL_PER_PAIRING, "mac_per_fp_mul": MAC_PER_FP_MUL}
         if world == 1 and not args.no_cpu_baseline and args.workload in ("pairing", "groth16"):   # (same value for groth16_prepared)
-            from blsutil import COracle
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from coracle import COracle
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
             sample = 768 * threads            # ~15 s of CPU work (about 1.2 ms per pairing and core on the GPU box)
-            cg1, cg2 = synthetic_batch(sample, jacobian=False, k=k, pool=64)
+            cg1, cg2 = g1[: sample * 12 * k], g2[: sample * 24 * k]
+            if args.workload == "groth16_prepared":
+                cg1, cg2 = synthetic.affine_batch(pools, sample, k, first)
             orc = COracle()
             orc.multi(cg1[: 12 * k * threads], cg2[: 24 * k * threads], k, final_exp=True, threads=threads)   # warm
             c0 = time.perf_counter()
             orc.multi(cg1, cg2, k, final_exp=True, threads=threads)
             cdt = time.perf_counter() - c0
             line["cpu_baseline"] = {"value": sample / cdt, "unit": line["unit"], "cores": threads, "kind": "port",
-                                    "sample": "%d units of the same synthetic workload, C restatement oracle/bls381_oracle.c "
+                                    "sample": "the first %d units of the same synthetic batch, C restatement oracle/bls381_oracle.c "
                                               "(same algorithm; the Rust reference cannot be built here), %.1f s wall" % (sample, cdt)}
         print(json.dumps(line), flush=True)
     if distributed:

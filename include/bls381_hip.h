@@ -45,7 +45,7 @@ typedef struct bls381_ctx bls381_ctx;
 
 enum {
   BLS381_OK = 0,
-  BLS381_E_INVALID = 1,     /* bad argument (NULL buffer, unsupported k, unknown op/option) */
+  BLS381_E_INVALID = 1,     /* bad argument (NULL buffer, k = 0, unknown op/option) */
   BLS381_E_NO_DEVICE = 2,   /* no usable gfx950 device / HIP runtime failure at create */
   BLS381_E_HIP = 3,         /* HIP runtime error during a call (bls381_last_hip_error) */
   BLS381_E_NOMEM = 4        /* device allocation failed */
@@ -62,11 +62,13 @@ enum {
 enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
        BLS381_OPT_FEXP_MODE = 3 /* how the final exponentiation (src/fields_as_trees/miller_loop.rs:128-178) is run; same output bits */,
        BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams (default 2) */,
-       BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch (k <= 3) walks its Miller loop with homogeneous-
+       BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch walks its Miller loop with homogeneous-
           projective curve steps (3 M + 6 S per doubling instead of Alg. 26's 3 M + 8 S, src/miller_loop_native.rs:27-55); the Miller
           value differs by an Fp2 factor that the final exponentiation kills, the pairing is bit-identical FOR POINTS ON THE CURVES
           (what arkworks' affine types hold); for other coordinate values only 0 reproduces the reference's arithmetic.
-          Miller-only entry points always follow Alg. 26/27. */ };
+          Miller-only entry points always follow Alg. 26/27. */,
+       BLS381_OPT_FEXP_CHUNK_LOG2 = 6 /* staged final exponentiation: a batch of more than 2^value elements runs in passes of 2^value
+          (10..22, default 20: ~8.9 GB of stage scratch).  Lower it to cap the scratch; the tests lower it to run the multi-pass path. */ };
 enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per element */
        BLS381_FEXP_BATCHED_INVERSION = 1, /* the Fp inversion under f^-1 (:175) from a batch-wide simultaneous inversion: three launches,
                                              64 B of context-owned device scratch per element */
@@ -114,13 +116,16 @@ int bls381_create(bls381_ctx** out, int device_id);
 void bls381_destroy(bls381_ctx* ctx);
 int bls381_set_option(bls381_ctx* ctx, int option, int value);
 int bls381_get_option(const bls381_ctx* ctx, int option, int* value);
-/* adopt an existing hipStream_t (e.g. the caller framework's current stream); NULL restores the own stream */
+/* Adopt an existing hipStream_t (e.g. the caller framework's current stream): the `_dev` entry points enqueue behind the work
+ * already queued on it.  NULL is a stream like any other -- the legacy default stream (handle 0, what torch calls its
+ * default stream).  A context starts on a private non-blocking stream of its own; bls381_use_own_stream returns to it. */
 int bls381_set_stream(bls381_ctx* ctx, void* hip_stream);
+int bls381_use_own_stream(bls381_ctx* ctx);
 int bls381_sync(bls381_ctx* ctx);
 const char* bls381_strerror(int code);
 int bls381_last_hip_error(const bls381_ctx* ctx);
-/* average device time of the last launch of the named kernel family on this context, in ms (HIP events
- * recorded on the context's stream around the launch); < 0 if none.  kernel: 0 ref_opt, 1 miller, 2 pairing */
+/* Device time in ms of the most recent pairing / Miller-loop / final-exponentiation call on this context (every launch of the
+ * call, between two HIP events recorded on the context's stream); waits for the call to finish; < 0 if there was none. */
 float bls381_last_kernel_ms(const bls381_ctx* ctx);
 
 /* Mode A: optimized_miller_loop over a batch (src/miller_loop_native_optimized.rs:81).
@@ -130,7 +135,10 @@ int bls381_miller_ref_opt_batch(bls381_ctx* ctx, const uint64_t* g1_jac, const u
 int bls381_miller_ref_opt_batch_dev(bls381_ctx* ctx, const uint64_t* g1_jac, const uint64_t* g2_jac,
                                     uint64_t* out_fq12, uint8_t* flags, size_t n);
 
-/* Mode B: product over k pairs of optimal-ate Miller loops (src/miller_loop_native.rs:154), k in 1..4.
+/* Mode B: product over k pairs of optimal-ate Miller loops -- `multi_miller_loop(terms: &[(&G1Affine, &G2Affine)])`,
+ * src/miller_loop_native.rs:154 -- for a slice of ANY length k >= 1.  Up to four pairs share one loop (one squaring per
+ * iteration for all of them, :100-106); longer products run in groups of three whose Miller values are multiplied on the
+ * device (the same field element: squaring distributes over the product), with one final exponentiation at the end.
  * g1_aff: n x k x 2 x 6, g2_aff: n x k x 2 x 2 x 6, out: n x 12 x 6. */
 int bls381_multi_miller_batch(bls381_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
                               uint64_t* out_fq12, uint8_t* flags, size_t n);

@@ -352,8 +352,9 @@ static void ell(fp12* f, const fp2 c[3], const g1a* p) {             /* commente
   fp2 c0, c1; fp2_mul_fp(&c0, &c[0], &p->y); fp2_mul_fp(&c1, &c[1], &p->x);
   fp12_mul_by_014(f, f, &c[2], &c1, &c0);
 }
+#define ORACLE_MAX_K 64   /* pairs per product (the reference takes a slice of any length, src/miller_loop_native.rs:154) */
 static void multi_miller(fp12* out, const g1a* p, const g2a* q, const int* skip, int k) {   /* :89-116, :154-212 */
-  g2j r[4]; fp2 c[3]; fp12 f = FP12_ONE_C;
+  g2j r[ORACLE_MAX_K]; fp2 c[3]; fp12 f = FP12_ONE_C;
   for (int j = 0; j < k; ++j) { r[j].x = q[j].x; r[j].y = q[j].y; memset(&r[j].z, 0, sizeof(fp2)); r[j].z.c0 = R1; }
   for (int b = 61; b >= 0; --b) {
     int bit = ((BLS_X >> 1) >> b) & 1;
@@ -421,7 +422,7 @@ static void run_range(const job_t* j) {
       g1j p; g2j q; memcpy(&p, j->a + 18 * i, 144); memcpy(&q, j->b + 36 * i, 288);
       fl = miller_ref_opt(&f, &p, &q) ? 1 : 0;
     } else if (j->kind == 1 || j->kind == 2) {
-      g1a p[4]; g2a q[4]; int skip[4]; size_t k = j->k;
+      g1a p[ORACLE_MAX_K]; g2a q[ORACLE_MAX_K]; int skip[ORACLE_MAX_K]; size_t k = j->k;
       for (size_t t = 0; t < k; ++t) {
         const uint64_t* pa = j->a + 12 * (k * i + t); const uint64_t* qa = j->b + 24 * (k * i + t);
         memcpy(&p[t], pa, 96); memcpy(&q[t], qa, 192);
@@ -458,11 +459,11 @@ int oracle_miller_ref_opt_batch(const uint64_t* g1_jac, const uint64_t* g2_jac, 
   return run_batch(0, g1_jac, g2_jac, 1, out, flags, n, threads);
 }
 int oracle_multi_miller_batch(const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k, uint64_t* out, uint8_t* flags, size_t n, int threads) {
-  if (k < 1 || k > 4) return 1;
+  if (k < 1 || k > ORACLE_MAX_K) return 1;
   return run_batch(1, g1_aff, g2_aff, k, out, flags, n, threads);
 }
 int oracle_multi_pairing_batch(const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k, uint64_t* out, uint8_t* flags, size_t n, int threads) {
-  if (k < 1 || k > 4) return 1;
+  if (k < 1 || k > ORACLE_MAX_K) return 1;
   return run_batch(2, g1_aff, g2_aff, k, out, flags, n, threads);
 }
 int oracle_final_exp_batch(const uint64_t* in, uint64_t* out, size_t n, int threads) {

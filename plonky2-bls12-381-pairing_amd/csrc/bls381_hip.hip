@@ -27,12 +27,18 @@ struct bls381_ctx {
   size_t raw_scratch_elems = 0;
   uint32_t* stage_scratch = nullptr; // staged form: lane-sliced stage values (csrc/fexp_stages.cuh)
   size_t stage_scratch_bytes = 0;
+  uint64_t* part_scratch = nullptr;  // products of more than four pairs: Miller value of the current group of pairs (n x 72 u64)
+  size_t part_scratch_elems = 0;
+  hipEvent_t part_done = nullptr;    // recorded behind the last launch that used part_scratch
+  hipStream_t part_stream = nullptr;
+  bool part_used = false;
   hipEvent_t scratch_done = nullptr; // recorded after the last launch that used raw_scratch
   // staged final exponentiation: the batch runs as two half-batch pipelines on two auxiliary streams, so that the ramp,
   // tail and stalls of one stage kernel (and the latency-bound inversion kernels) overlap with the other half's work
   static constexpr int MAX_PIPES = 4;
   int pipes = 2;                     // BLS381_OPT_FEXP_PIPELINES
   int hom_miller = 1;                // BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER
+  int fexp_chunk_log2 = 20;          // BLS381_OPT_FEXP_CHUNK_LOG2: staged form, elements per pass (bounds the stage scratch)
   hipStream_t aux[MAX_PIPES] = {};
   hipEvent_t fork = nullptr, stagger[MAX_PIPES] = {}, join[MAX_PIPES] = {};
   hipStream_t scratch_stream = nullptr;
@@ -70,6 +76,7 @@ int bls381_create(bls381_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->part_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) {
     bls381_destroy(c);
     return BLS381_E_NO_DEVICE;
@@ -94,7 +101,9 @@ void bls381_destroy(bls381_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->raw_scratch) (void)hipFree(c->raw_scratch);
   if (c->stage_scratch) (void)hipFree(c->stage_scratch);
+  if (c->part_scratch) (void)hipFree(c->part_scratch);
   if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
+  if (c->part_done) (void)hipEventDestroy(c->part_done);
   for (int i = 0; i < bls381_ctx::MAX_PIPES; ++i) {
     if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     if (c->join[i]) (void)hipEventDestroy(c->join[i]);
@@ -121,6 +130,9 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
       if (value < 1 || value > bls381_ctx::MAX_PIPES) return BLS381_E_INVALID;
       c->pipes = value; return BLS381_OK;
     case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: c->hom_miller = value ? 1 : 0; return BLS381_OK;
+    case BLS381_OPT_FEXP_CHUNK_LOG2:
+      if (value < 10 || value > 22) return BLS381_E_INVALID;
+      c->fexp_chunk_log2 = value; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -134,13 +146,20 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_FEXP_MODE: *value = c->fexp_mode; return BLS381_OK;
     case BLS381_OPT_FEXP_PIPELINES: *value = c->pipes; return BLS381_OK;
     case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: *value = c->hom_miller; return BLS381_OK;
+    case BLS381_OPT_FEXP_CHUNK_LOG2: *value = c->fexp_chunk_log2; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
 
 int bls381_set_stream(bls381_ctx* c, void* s) {
   if (!c) return BLS381_E_INVALID;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;          // NULL is a stream too: the legacy default stream
+  return BLS381_OK;
+}
+
+int bls381_use_own_stream(bls381_ctx* c) {
+  if (!c) return BLS381_E_INVALID;
+  c->stream = c->own_stream;
   return BLS381_OK;
 }
 
@@ -176,7 +195,6 @@ struct Timed {
 // asynchronous, so a previous call may still be using the buffers: on the same stream the order is implicit; after
 // bls381_set_stream the new stream first waits for the event recorded behind the last user; an outgrown buffer is released
 // only after that user has finished.
-constexpr size_t FEXP_CHUNK = (size_t)1 << 20;      // staged form: elements per pass (bounds the stage scratch at ~8.9 GB)
 constexpr size_t FEXP_AUTO_STAGED_MIN = (size_t)1 << 19; // BLS381_FEXP_AUTO: staged form from this batch size on
 constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14; // staged form: from this many elements on, two half-batch pipelines
 
@@ -190,7 +208,8 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   if (c->scratch_used && c->scratch_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->scratch_done, 0));
   bool staged = c->fexp_mode == BLS381_FEXP_STAGED || (c->fexp_mode == BLS381_FEXP_AUTO && n >= FEXP_AUTO_STAGED_MIN);
   // raw scratch always covers the whole batch (the batched-inversion form, also the fallback, is not chunked)
-  const size_t chunk = (staged && n > FEXP_CHUNK) ? FEXP_CHUNK : n;
+  const size_t max_chunk = (size_t)1 << c->fexp_chunk_log2;   // 2^20 by default: bounds the stage scratch at ~8.9 GB
+  const size_t chunk = (staged && n > max_chunk) ? max_chunk : n;
   // staged: every pipeline owns a share of fexp_part(chunk) elements of both scratches
   const size_t stage_bytes = staged ? (size_t)c->pipes * bls_launch::fexp_stage_scratch_bytes(fexp_part(chunk, c->pipes)) : 0;
   const size_t raw_elems = staged ? (n > (size_t)c->pipes * fexp_part(chunk, c->pipes) ? n : (size_t)c->pipes * fexp_part(chunk, c->pipes)) : n;
@@ -267,16 +286,47 @@ int launch_ref_opt(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64
   return BLS381_OK;
 }
 
+// Pairs per Miller launch for a product of k pairs: up to four pairs go in one launch (shared squarings); longer products
+// are cut into groups of three (the largest group whose state stays in registers), the groups' Miller values are multiplied
+// on the device (bit-identical to one shared loop: squaring distributes over the product) and ONE final exponentiation
+// follows -- `multi_miller_loop(terms: &[..])` takes a slice of any length (src/miller_loop_native.rs:154-212).
+constexpr size_t MULTI_GROUP = 3;
+
+int part_acquire(bls381_ctx* c, size_t n) {
+  if (c->part_used && c->part_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->part_done, 0));
+  if (c->part_scratch_elems >= n) return BLS381_OK;
+  if (c->part_used) HIP_TRY(c, hipEventSynchronize(c->part_done));
+  if (c->part_scratch) { (void)hipFree(c->part_scratch); c->part_scratch = nullptr; c->part_scratch_elems = 0; }
+  HIP_TRY(c, hipMalloc((void**)&c->part_scratch, n * 72 * sizeof(uint64_t)));
+  c->part_scratch_elems = n;
+  return BLS381_OK;
+}
+
 template <bool FE>
 int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
   if (n == 0) return BLS381_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   FexpPlan plan;
   if (FE) { const int rc = fexp_acquire(c, n, &plan); if (rc != BLS381_OK) return rc; }
+  if (k > 4) { const int rc = part_acquire(c, n); if (rc != BLS381_OK) return rc; }
   int rc = BLS381_OK;
   {
     Timed t(c);
-    if (!bls_launch::multi(k, FE && c->hom_miller, g1, g2, out, flags, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
+    const bool hom = FE && c->hom_miller;
+    if (k <= 4) {
+      if (!bls_launch::multi(k, hom, g1, g2, k, out, flags, false, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
+    } else {
+      for (size_t first = 0; first < k; first += MULTI_GROUP) {
+        const size_t kc = (k - first < MULTI_GROUP) ? k - first : MULTI_GROUP;
+        uint64_t* dst = first ? c->part_scratch : out;
+        if (!bls_launch::multi(kc, hom, g1 + 12 * first, g2 + 24 * first, k, dst, flags, first != 0, n, c->io_form, c->block, c->stream))
+          return BLS381_E_INVALID;
+        if (first) bls_launch::fp12_op(BLS381_FP12_MUL, out, c->part_scratch, out, n, c->io_form, c->block, c->stream);
+      }
+      HIP_TRY(c, hipEventRecord(c->part_done, c->stream));
+      c->part_stream = c->stream;
+      c->part_used = true;
+    }
     if (FE) rc = fexp_launch(c, plan, out, out, nullptr, n);
   }
   if (rc != BLS381_OK) return rc;
@@ -340,24 +390,24 @@ int bls381_miller_ref_opt_batch(bls381_ctx* c, const uint64_t* g1, const uint64_
 }
 
 int bls381_multi_miller_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
-  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (!c || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   return launch_multi<false>(c, g1, g2, k, out, flags, n);
 }
 
 int bls381_multi_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
-  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (!c || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   return launch_multi<true>(c, g1, g2, k, out, flags, n);
 }
 
 int bls381_multi_miller_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
-  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (!c || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   return with_staging(c, g1, n * k * 96, g2, n * k * 192, out, n * 576, flags, n,
                       [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_multi<false>(c, a, b, k, o, f, n); });
 }
 
 int bls381_multi_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
-  if (!c || k < 1 || k > 4 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  if (!c || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   return with_staging(c, g1, n * k * 96, g2, n * k * 192, out, n * 576, flags, n,
                       [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_multi<true>(c, a, b, k, o, f, n); });

@@ -36,7 +36,7 @@ k_fp_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, 
 }
 
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_fp12_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out, size_t n, int form) {
+k_fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form) {   // out may be a or b (in place)
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   const Fp12R x = fp12_load(a + 72 * i, form);
@@ -196,12 +196,13 @@ void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s) {
   const size_t chunks = (n + FP_BATCH_INV_CHUNK - 1) / FP_BATCH_INV_CHUNK;
   hipLaunchKernelGGL(k_fp_batch_inv, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, raw, n);
 }
-bool multi(size_t k, bool hom, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+bool multi(size_t k, bool hom, const uint64_t* g1, const uint64_t* g2, size_t stride, uint64_t* out, uint8_t* flags, bool flags_or,
+           size_t n, int form, int block, hipStream_t s) {
   switch (k) {
-    case 1: multi_k1(hom, g1, g2, out, flags, n, form, block, s); return true;
-    case 2: multi_k2(hom, g1, g2, out, flags, n, form, block, s); return true;
-    case 3: multi_k3(hom, g1, g2, out, flags, n, form, block, s); return true;
-    case 4: multi_k4(hom, g1, g2, out, flags, n, form, block, s); return true;
+    case 1: multi_k1(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
+    case 2: multi_k2(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
+    case 3: multi_k3(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
+    case 4: multi_k4(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
     default: return false;
   }
 }

@@ -18,8 +18,8 @@ static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bl
 // HOM: homogeneous-projective curve steps (pairing.cuh) -- for launches that are followed by the final exponentiation
 template <int K, bool HOM>
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
-k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, uint64_t* __restrict__ out,
-               uint8_t* __restrict__ flags, size_t n, int form) {
+k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, size_t stride, uint64_t* __restrict__ out,
+               uint8_t* __restrict__ flags, int flags_or, size_t n, int form) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_ELEM;
   if (i >= n) return;
   G1Aff p[K]; G2Aff q[K]; bool skip[K];
@@ -27,22 +27,23 @@ k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2,
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     bool i1, i2;
-    p[j] = g1_aff_load(g1 + 12 * (K * i + j), form, i1);
-    q[j] = g2_aff_load(g2 + 24 * (K * i + j), form, i2);
+    p[j] = g1_aff_load(g1 + 12 * (stride * i + j), form, i1);      // stride = pairs per element in the caller's arrays (>= K)
+    q[j] = g2_aff_load(g2 + 24 * (stride * i + j), form, i2);
     skip[j] = i1 || i2;
     if (skip[j]) fl |= FLAG_INFINITY;
   }
   const Fp12R f = miller_ate<K, HOM>(p, q, skip);
   fp12_store(out + 72 * i, f, form);
-  if (flags && lane_part() == 0) flags[i] = fl;
+  if (flags && lane_part() == 0) flags[i] = flags_or ? (uint8_t)(flags[i] | fl) : fl;
 }
 
 namespace bls_launch {
 // A full pairing is this Miller kernel (one wave per SIMD, ~460 registers per lane, no scratch) followed by a final
 // exponentiation in place on `out` (k_fexp.hip: its own translation unit, compiled for two waves per SIMD, where it
 // runs ~15 % faster than inside a fused kernel).  The intermediate Fq12 costs 2 x 576 B of HBM traffic per pairing.
-void BLS_CAT(multi_k, BLS_K)(bool hom, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
-  if (hom) hipLaunchKernelGGL((k_multi_miller<BLS_K, true>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
-  else hipLaunchKernelGGL((k_multi_miller<BLS_K, false>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
+void BLS_CAT(multi_k, BLS_K)(bool hom, const uint64_t* g1, const uint64_t* g2, size_t stride, uint64_t* out, uint8_t* flags, bool flags_or,
+                             size_t n, int form, int block, hipStream_t s) {
+  if (hom) hipLaunchKernelGGL((k_multi_miller<BLS_K, true>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, stride, out, flags, (int)flags_or, n, form);
+  else hipLaunchKernelGGL((k_multi_miller<BLS_K, false>), dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, stride, out, flags, (int)flags_or, n, form);
 }
 }  // namespace bls_launch

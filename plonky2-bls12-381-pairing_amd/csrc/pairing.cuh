@@ -361,6 +361,8 @@ BLS_HD Fp12R ell(const Fp12R& f, const LineCoeffs& l, const G1Aff& p) {
 }
 BLS_HD_NOINLINE LineCoeffs doubling_step_call(G2Jac& r) { return doubling_step(r); }
 BLS_HD_NOINLINE LineCoeffs addition_step_call(G2Jac& r, const G2Aff& q) { return addition_step(r, q); }
+BLS_HD_NOINLINE LineCoeffs doubling_step_hom_call(G2Jac& r) { return doubling_step_hom(r); }
+BLS_HD_NOINLINE LineCoeffs addition_step_hom_call(G2Jac& r, const G2Aff& q) { return addition_step_hom(r, q); }
 BLS_HD_NOINLINE Fp12R ell_call(const Fp12R& f, const LineCoeffs& l, const G1Aff& p) { return ell(f, l, p); }
 
 // Miller loop over N_PAIRS pairs with shared squarings: src/miller_loop_native.rs:89-116 driven the way
@@ -394,10 +396,8 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
       } else {
 #pragma unroll
         for (int j = 0; j < N_PAIRS; ++j) {
-          // always Alg. 26/27 here: an out-of-line homogeneous addition step comes out of hipcc (ROCm 7.2) computing a
-          // different point than the same source inlined (tools/kbench/dbg_hom.hip reproduces it; the returned line is
-          // right, the updated point is not) -- and this path (more than three pairs) is not a hot one
-          const LineCoeffs l = (pass == 0) ? doubling_step_call(r[j]) : addition_step_call(r[j], q[j]);
+          const LineCoeffs l = HOM ? ((pass == 0) ? doubling_step_hom_call(r[j]) : addition_step_hom_call(r[j], q[j]))
+                                   : ((pass == 0) ? doubling_step_call(r[j]) : addition_step_call(r[j], q[j]));
           if (!skip[j]) f = ell_call(f, l, p[j]);
         }
       }

@@ -115,7 +115,7 @@ inline void pack_terms(const std::vector<std::pair<const G1Affine*, const G2Affi
 }  // namespace detail
 
 /// src/miller_loop_native.rs:154 with the line evaluation live (the reference's body is commented out and returns
-/// one; `MillerLoopResult::one` reproduces that literal behaviour).  terms.size() must be 1..4 per call.
+/// one; `MillerLoopResult::one` reproduces that literal behaviour).  Any number of terms, like the reference's slice.
 inline MillerLoopResult multi_miller_loop(const Backend& be, const std::vector<std::pair<const G1Affine*, const G2Affine*>>& terms) {
   if (terms.empty()) return MillerLoopResult::one(be);
   std::vector<uint64_t> g1, g2;

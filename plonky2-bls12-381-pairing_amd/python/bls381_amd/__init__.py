@@ -19,6 +19,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hi
 
 IO_ARK_MONT, IO_CANONICAL = 0, 1
 OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE, OPT_FEXP_MODE, OPT_FEXP_PIPELINES, OPT_PAIRING_HOMOGENEOUS_MILLER = 0, 1, 2, 3, 4, 5
+OPT_FEXP_CHUNK_LOG2 = 6
 FEXP_SELF_CONTAINED, FEXP_BATCHED_INVERSION, FEXP_STAGED, FEXP_AUTO = 0, 1, 2, 3
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_TRUE = 32
@@ -31,7 +32,7 @@ FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP
 
 # every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "bls381_create", "bls381_destroy", "bls381_set_option", "bls381_get_option", "bls381_set_stream",
+    "bls381_create", "bls381_destroy", "bls381_set_option", "bls381_get_option", "bls381_set_stream", "bls381_use_own_stream",
     "bls381_sync", "bls381_strerror", "bls381_last_hip_error", "bls381_last_kernel_ms",
     "bls381_miller_ref_opt_batch", "bls381_miller_ref_opt_batch_dev",
     "bls381_multi_miller_batch", "bls381_multi_miller_batch_dev",
@@ -64,6 +65,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.bls381_get_option.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     lib.bls381_set_stream.argtypes = [vp, vp]
+    lib.bls381_use_own_stream.argtypes = [vp]
     lib.bls381_sync.argtypes = [vp]
     lib.bls381_strerror.argtypes = [ctypes.c_int]
     lib.bls381_strerror.restype = ctypes.c_char_p
@@ -146,7 +148,11 @@ class Engine:
         return v.value
 
     def set_stream(self, hip_stream: int | None):
-        self._check(self.lib.bls381_set_stream(self._ctx, ctypes.c_void_p(hip_stream or 0)), "bls381_set_stream")
+        """Adopt a hipStream_t handle (0 = the legacy default stream); None returns to the context's own stream."""
+        if hip_stream is None:
+            self._check(self.lib.bls381_use_own_stream(self._ctx), "bls381_use_own_stream")
+        else:
+            self._check(self.lib.bls381_set_stream(self._ctx, ctypes.c_void_p(hip_stream)), "bls381_set_stream")
 
     def sync(self):
         self._check(self.lib.bls381_sync(self._ctx), "bls381_sync")

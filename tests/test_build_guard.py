@@ -50,3 +50,39 @@ def test_current_build_is_clean():
         pytest.skip("no build directory (library built elsewhere)")
     for f in files:
         assert chk.check(f) == [], f
+
+
+REV_DPP = """
+	.amdhsa_kernel k2
+k2:
+	v_mov_b32_dpp v1, v0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_add_u32_dpp v2, v0, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_sub_u32_dpp v2, v0, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_subrev_f32_dpp v2, v0, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_subrev_u32_dpp v2, v48, v48 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_subrev_co_u32_dpp v2, vcc, v48, v48 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_lshlrev_b32_dpp v2, v3, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1
+	s_endpgm
+"""
+
+
+def test_checker_flags_reversed_operand_integer_dpp(tmp_path):
+    """gfx950 executes v_subrev_u32_dpp / v_lshlrev_b32_dpp with the lane permutation on the other operand than LLVM's DPP
+    combiner assumes (tools/microbench/dpp_sub_probe.hip): any such instruction fails the build.  The
+    commutative and the non-reversed forms, and the float subrev, are fine."""
+    f = tmp_path / "rev.s"
+    f.write_text(REV_DPP)
+    assert chk.rev_dpp_uses(str(f)) == [("v_lshlrev_b32_dpp", 1), ("v_subrev_co_u32_dpp", 1), ("v_subrev_u32_dpp", 1)]
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_device_asm.py"), str(f)]) == 1
+    ok = tmp_path / "ok.s"
+    ok.write_text("\n".join(l for l in REV_DPP.split("\n") if "rev_u32" not in l and "rev_co" not in l and "lshlrev" not in l))
+    assert chk.rev_dpp_uses(str(ok)) == []
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_device_asm.py"), str(ok)]) == 0
+
+
+def test_current_build_has_no_reversed_operand_dpp_and_disables_the_combiner():
+    files = glob.glob(os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "build", "*", "*gfx950.s"))
+    for f in files:
+        assert chk.rev_dpp_uses(f) == [], f
+    mk = open(os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "Makefile")).read()
+    assert "-amdgpu-dpp-combine=false" in mk

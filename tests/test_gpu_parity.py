@@ -225,10 +225,16 @@ def test_mode_b_golden(engine):
     assert np.array_equal(engine.final_exponentiation(out), engine.multi_pairing(g1, g2, 3)[0])
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 9])
 def test_mode_b_vs_c_oracle_batch(engine, coracle, k):
+    """Products of k pairs (`multi_miller_loop(terms: &[..])` takes any length, src/miller_loop_native.rs:154): one launch up to
+    k = 4 (k = 4 through the out-of-line homogeneous steps), groups of three multiplied on the device beyond; pairs at
+    infinity in the first and in a later group (their flag must survive the later groups' launches)."""
     n = 300 + k
     g1, g2 = synthetic_batch(n, seed=9000 + k, jacobian=False, k=k, pool=50)
+    g1 = g1.copy(); g2 = g2.copy()
+    g1.reshape(n, k, 12)[3, 0] = 0                       # element 3: first pair at infinity
+    g2.reshape(n, k, 24)[5, k - 1] = 0                   # element 5: last pair at infinity
     exp, efl = coracle.multi(g1, g2, k, final_exp=True, threads=16)
     out, fl = engine.multi_pairing(g1, g2, k)
     assert np.array_equal(out, exp) and np.array_equal(fl, efl)
@@ -274,8 +280,9 @@ def test_canonical_io_and_empty_and_errors(engine):
     assert out.size == 0 and fl.size == 0
     out, fl = engine.optimized_miller_loop(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64))
     assert out.size == 0
-    with pytest.raises(B.Bls381Error):
-        engine.multi_pairing(np.zeros(12 * 5, dtype=np.uint64), np.zeros(24 * 5, dtype=np.uint64), 5)   # k out of range
+    import ctypes
+    z = np.zeros(72, dtype=np.uint64); zp = z.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert engine.lib.bls381_multi_pairing_batch(engine._ctx, zp, zp, 0, zp, None, 1) == 1               # k = 0: BLS381_E_INVALID
     with pytest.raises(B.Bls381Error):
         engine.set_option(B.OPT_BLOCK_SIZE, 100)
     with pytest.raises(AssertionError):
@@ -284,22 +291,112 @@ def test_canonical_io_and_empty_and_errors(engine):
     assert all(O.fp12_is_one(x) for x in one)                                                            # config 0 / SURVEY F4
 
 
-def test_full_size_batch_properties(engine, coracle):
-    """BASELINE size (2^20 full pairings): the batch tiles a 64-element pool, so (1) the first period must equal the
-    oracle and (2) every later period must equal the first, bit for bit -- a checksum of checksums over 604 MB."""
+@pytest.fixture(scope="module")
+def pools(engine):
+    """4096-point pools (k+1) G1 / (k+1) G2 built on the GPU by the library's own point kernels."""
+    from bls381_amd import synthetic
+    return synthetic.build_pools(engine, 4096)
+
+
+def _oracle_sample(coracle, g1, g2, out, n, count, w1=12, w2=24):
+    idx = (np.arange(count, dtype=np.int64) * (n // count)) % n
+    idx[-1] = n - 1                                            # always include the very last element
+    exp, _ = coracle.multi(np.ascontiguousarray(g1.reshape(n, w1)[idx]).reshape(-1), np.ascontiguousarray(g2.reshape(n, w2)[idx]).reshape(-1),
+                           1, final_exp=True, threads=16)
+    return np.array_equal(out.reshape(n, 72)[idx].reshape(-1), exp)
+
+
+def test_synthetic_pools_are_the_multiples_of_the_generators(engine, pools):
+    """Pool entry k is (k+1) G: entries 0, 1, 2, 1000, 4095 against big-integer scalar multiplication."""
+    p1, p2 = pools
+    for k in (0, 1, 2, 1000, 4095):
+        assert dec_fps(p1[k]) == list(O.g1_mul(k + 1)), k
+        q = O.g2_mul(k + 1)
+        assert dec_fps(p2[k]) == [q[0][0], q[0][1], q[1][0], q[1][1]], k
+
+
+def test_full_size_batch_properties(engine, coracle, pools):
+    """BASELINE size (2^20 full pairings) on 2^19 DISTINCT pairings: element i + 2^19 pairs the same multiples the other way
+    round, e((a+1) G1, (b+1) G2) = e((b+1) G1, (a+1) G2), so (1) the two halves must be equal bit for bit -- 302 MB against
+    302 MB, no two compared elements computed from the same inputs -- and (2) 4096 elements spread over the batch must equal
+    the oracle."""
+    from bls381_amd import synthetic
     n = 1 << 20
-    pool = 64
-    g1, g2 = synthetic_batch(n, jacobian=False, pool=pool)
+    g1, g2 = synthetic.mirrored_affine_batch(pools, n)
     out, fl = engine.multi_pairing(g1, g2, 1)
-    o = out.reshape(n // pool, pool * 72)
-    exp, _ = coracle.multi(g1[: pool * 12], g2[: pool * 24], 1, final_exp=True, threads=16)
-    assert np.array_equal(o[0], exp)
-    assert (o == o[0]).all()
     assert not fl.any()
+    o = out.reshape(2, n // 2, 72)
+    assert np.array_equal(o[0], o[1])
+    # really distinct pairings, not a tiled pool (e depends on (a+1)(b+1) mod r only, so some index pairs coincide in value)
+    assert len(np.unique(o[0][:, :6], axis=0)) > (n // 2) * 0.8
+    assert _oracle_sample(coracle, g1, g2, out, n, 4096)
+
+
+def test_staged_fexp_multi_pass_small_chunks(engine, coracle):
+    """The `first > 0` passes of the staged final exponentiation (batches above the chunk size) with the chunk lowered to
+    2^12: n = 2 chunks + 77 at one and at two pipelines, every element against the oracle."""
+    n = 2 * 4096 + 77
+    g1, g2 = synthetic_batch(n, seed=4242, jacobian=False, pool=64)
+    exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
+    try:
+        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_STAGED)
+        engine.set_option(B.OPT_FEXP_CHUNK_LOG2, 12)
+        for pipes in (1, 2, 3):
+            engine.set_option(B.OPT_FEXP_PIPELINES, pipes)
+            out, fl = engine.multi_pairing(g1, g2, 1)
+            assert np.array_equal(out, exp) and np.array_equal(fl, efl), pipes
+    finally:
+        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_AUTO); engine.set_option(B.OPT_FEXP_CHUNK_LOG2, 20); engine.set_option(B.OPT_FEXP_PIPELINES, 2)
+
+
+def test_staged_fexp_above_one_chunk_full_size(engine, coracle, pools):
+    """n = 2^20 + 2^19 + 77 with the default chunk of 2^20: the second pass and its pipelines at production size.  Checked
+    against the batched-inversion form (a different code path, one pass) on every element and against the oracle on a sample."""
+    from bls381_amd import synthetic
+    n = (1 << 20) + (1 << 19) + 77
+    g1, g2 = synthetic.affine_batch(pools, n, 1, first=12345)
+    out, fl = engine.multi_pairing(g1, g2, 1)                               # AUTO -> staged, two passes
+    try:
+        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_BATCHED_INVERSION)
+        out2, fl2 = engine.multi_pairing(g1, g2, 1)
+    finally:
+        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_AUTO)
+    assert np.array_equal(out, out2) and not fl.any() and not fl2.any()
+    assert _oracle_sample(coracle, g1, g2, out, n, 1024)
+
+
+@pytest.mark.parametrize("n", [(1 << 19) - 64, 1 << 19])
+def test_fexp_auto_both_sides_of_the_switch(engine, coracle, pools, n):
+    """BLS381_FEXP_AUTO picks the batched-inversion form below 2^19 elements and the staged form from 2^19 on."""
+    from bls381_amd import synthetic
+    g1, g2 = synthetic.mirrored_affine_batch(pools, n, first=777)
+    out, fl = engine.multi_pairing(g1, g2, 1)
+    o = out.reshape(2, n // 2, 72)
+    assert np.array_equal(o[0], o[1]) and not fl.any()
+    assert _oracle_sample(coracle, g1, g2, out, n, 512)
+
+
+def test_miller_only_64k_generic_mode_a_and_mode_b(engine, coracle, pools):
+    """configs[1] at full size (2^16 Miller loops, no final exponentiation), every element against the oracle: Mode A as the
+    reference computes it (generic Fq12 accumulators, general-Z inputs) and Mode B (Alg. 26/27)."""
+    from bls381_amd import synthetic
+    n = 1 << 16
+    j1, j2 = synthetic.jacobian_batch(engine, pools, n, first=99)
+    assert engine.get_option(B.OPT_REF_OPT_FP2_SHORTCUT) == 0
+    out, fl = engine.optimized_miller_loop(j1, j2)
+    exp, efl = coracle.miller_ref_opt(j1, j2, threads=16)
+    assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+    a1, a2 = synthetic.affine_batch(pools, n, 1, first=99)
+    outm, flm = engine.multi_miller_loop(a1, a2, 1)
+    expm, eflm = coracle.multi(a1, a2, 1, final_exp=False, threads=16)
+    assert np.array_equal(outm, expm) and np.array_equal(flm, eflm)
+    # the Jacobian inputs are representatives of the same points: normalising them gives the affine batch back
+    nrm, _ = engine.point_op(2, B.POINT_NORMALIZE, j2)
+    assert np.array_equal(nrm.reshape(n, 36)[:, :24].reshape(-1), a2)
 
 
 def test_mode_a_64k_batch_properties(engine, coracle):
-    """configs[1] size (2^16 Miller loops, Mode A)."""
+    """configs[1] size (2^16 Miller loops, Mode A) with the Fp2 shortcut."""
     n = 1 << 16
     pool = 64
     g1, g2 = synthetic_batch(n, jacobian=True, pool=pool)
