@@ -28,8 +28,9 @@
  *   - Return value 0 = success, otherwise a BLS381_E_* code (bls381_strerror).  Where the reference would
  *     panic, the element's output is zeroed and its flags[i] byte says why; flags may be NULL.
  *   - Results are bit-identical for every batch size, device and option setting.
- *   - A context is bound to ONE device; multi-GPU use = one context (normally one process) per GPU with the
- *     batch split in contiguous ranges -- elements are independent, nothing is exchanged between devices.
+ *   - A context is bound to ONE device; multi-GPU use = one context per GPU with the batch split in contiguous
+ *     ranges -- elements are independent, nothing is exchanged between devices: either one process per GPU
+ *     (bls381_amd/sharding.py, torch.distributed) or one process with a bls381_multi (end of this file).
  */
 #ifndef BLS381_HIP_H
 #define BLS381_HIP_H
@@ -109,7 +110,10 @@ enum { BLS381_POINT_ADD = 0        /* ark-ec 0.4.2 `Projective += &Projective` (
                                       infinity -> (1, 1, 0) */,
        BLS381_POINT_EQ = 3         /* point equality, flags bit BLS381_FLAG_TRUE (`is_point_equal_to`, g2_curve.rs:129-149,
                                       g1_curve.rs:79-110: both at infinity, or neither and equal coordinates) */,
-       BLS381_POINT_IS_ON_CURVE = 4 /* Y^2 == X^3 + b Z^6, b = 4 (G1) / 4(1+u) (G2); flags bit BLS381_FLAG_TRUE */ };
+       BLS381_POINT_IS_ON_CURVE = 4 /* Y^2 == X^3 + b Z^6, b = 4 (G1) / 4(1+u) (G2); flags bit BLS381_FLAG_TRUE */,
+       BLS381_POINT_IS_IN_SUBGROUP = 5 /* on the curve AND [r] P == infinity (r at src/miller_loop_native_optimized.rs:110): what
+                                          arkworks checks when it deserialises a `G1Affine` / `G2Affine` [third party]; the pairing
+                                          entry points assume it.  flags bit BLS381_FLAG_TRUE */ };
 
 /* lifecycle ------------------------------------------------------------------------------------------ */
 int bls381_create(bls381_ctx** out, int device_id);
@@ -197,12 +201,22 @@ int bls381_fp_pow_batch(bls381_ctx* ctx, const uint64_t* a, const uint64_t* exp,
  * BLS381_FLAG_INFINITY, as the reference does (:58-60). */
 int bls381_g2_prepare_batch(bls381_ctx* ctx, const uint64_t* g2_aff, uint64_t* coeffs, uint8_t* flags, size_t n);
 
-/* G1 / G2 point ops (src/curves/*, src/fields_as_trees/g{1,2}_curve.rs; arkworks group law at opt.rs:93,98).
+/* G1 / G2 point ops (src/curves/, src/fields_as_trees/g{1,2}_curve.rs; arkworks group law at opt.rs:93,98).
  * a, b, out: n x 3 x 6 u64 (G1) / n x 3 x 2 x 6 (G2) Jacobian points; b is read by ADD and EQ only.  ADD / DOUBLE / NORMALIZE
- * write `out` (flags optional: BLS381_FLAG_INFINITY when the result is the point at infinity); EQ / IS_ON_CURVE answer in
- * `flags` (required) and leave `out` untouched (may be NULL). */
+ * write `out` (flags optional: BLS381_FLAG_INFINITY when the result is the point at infinity); EQ / IS_ON_CURVE / IS_IN_SUBGROUP
+ * answer in `flags` (required) and leave `out` untouched (may be NULL). */
 int bls381_g1_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n);
 int bls381_g2_op_batch(bls381_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n);
+
+/* Point decompression, from the reference's own pieces: out[i] = the AFFINE point (x, y) with the given abscissa,
+ * y^2 = x^3 + 4 (G1) / x^3 + 4 (1 + u) (G2), whose ordinate satisfies sgn0(y) == sign[i] & 1 -- sgn0_fq / sgn0_fq2 of
+ * src/fields/helpers.rs:159-174 (parity of the canonical integer; for Fq2 of c0, or of c1 when c0 == 0), the square roots of
+ * FqSqrtGenerator / Fq2SqrtGenerator (src/fields/fq_target.rs:330-343, src/fields/fq2_target.rs:385-410).  sign[i] & 2 marks the
+ * point at infinity (all-zero output, BLS381_FLAG_INFINITY).  x that is not an abscissa of the curve: all-zero output and
+ * BLS381_FLAG_NOT_SQUARE.  Subgroup membership is a separate question (BLS381_POINT_IS_IN_SUBGROUP).
+ * x: n x 6 u64 (G1) / n x 2 x 6 (G2) in the context's encoding; out_aff: n x 2 x 6 / n x 2 x 2 x 6; sign: n bytes. */
+int bls381_g1_decompress_batch(bls381_ctx* ctx, const uint64_t* x, const uint8_t* sign, uint64_t* out_aff, uint8_t* flags, size_t n);
+int bls381_g2_decompress_batch(bls381_ctx* ctx, const uint64_t* x, const uint8_t* sign, uint64_t* out_aff, uint8_t* flags, size_t n);
 
 /* Witness-generator backend: batch forms of the `SimpleGenerator::run_once` hooks through which
  * plonky2 invokes native arithmetic while filling a witness.  Elements are CANONICAL integers as 12 x u32
@@ -239,6 +253,29 @@ int bls381_debug_line_ref_opt_batch(bls381_ctx* ctx, const uint64_t* q1_jac, con
 /* What src/miller_loop_native.rs:154-212 returns TODAY for any input (its line steps are commented out):
  * Fq12::one().  Host-only, here so that a caller can reproduce the literal reference behaviour. */
 int bls381_multi_miller_literal(bls381_ctx* ctx, uint64_t* out_fq12, size_t n);
+
+/* Several devices behind ONE host process (BASELINE configs "2^23 pairings / 3 x 2^18 proofs across 8 GPUs" for a
+ * caller that is a single program, like the reference's).  A bls381_multi owns one context per listed device
+ * (device_ids == NULL or n_devices <= 0: every visible device; an id may be listed more than once).  The `_sharded` calls cut the
+ * batch into contiguous ranges [g n / G, (g + 1) n / G), one per context, and run each range through that device's host-pointer
+ * entry point on its own host thread -- double-buffered copies on the context's copy streams, kernels on its compute stream.
+ * Elements are independent, so nothing is exchanged between devices; results are bit-identical to the one-device call.
+ * With a single context this IS the one-device call. */
+typedef struct bls381_multi bls381_multi;
+int bls381_create_multi(bls381_multi** out, const int* device_ids, int n_devices);
+void bls381_destroy_multi(bls381_multi* m);
+int bls381_multi_device_count(const bls381_multi* m);
+bls381_ctx* bls381_multi_context(bls381_multi* m, int index);           /* e.g. to query one device's last_kernel_ms */
+int bls381_multi_set_option(bls381_multi* m, int option, int value);    /* on every context */
+/* multi_miller_loop over n independent k-pair products followed by the final exponentiation (src/miller_loop_native.rs:154,
+ * src/fields_as_trees/miller_loop.rs:128-178); same buffers as bls381_multi_pairing_batch */
+int bls381_multi_pairing_batch_sharded(bls381_multi* m, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
+                                       uint64_t* out_gt, uint8_t* flags, size_t n);
+int bls381_multi_miller_batch_sharded(bls381_multi* m, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t k,
+                                      uint64_t* out_fq12, uint8_t* flags, size_t n);
+/* optimized_miller_loop (src/miller_loop_native_optimized.rs:81); same buffers as bls381_miller_ref_opt_batch */
+int bls381_miller_ref_opt_batch_sharded(bls381_multi* m, const uint64_t* g1_jac, const uint64_t* g2_jac,
+                                        uint64_t* out_fq12, uint8_t* flags, size_t n);
 
 #ifdef __cplusplus
 }

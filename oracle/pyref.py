@@ -1001,6 +1001,31 @@ def witness_fq2_sqrt(x, sgn):
     return s, 0
 
 
+def jac_in_subgroup(F, pt):
+    """On the curve and [r] pt == infinity (arkworks `is_in_correct_subgroup_assuming_on_curve` after `is_on_curve`
+    [third party]; r: the decimal at src/miller_loop_native_optimized.rs:110)."""
+    if not jac_on_curve(F, pt):
+        return False
+    return F.is_zero(jac_scalar_mul(F, pt, R_ORDER)[2])
+
+
+def decompress_point(group, x, sgn):
+    """Affine point with abscissa x and sgn0(y) == sgn & 1, from the reference's pieces: curve equation
+    (src/curves/g{1,2}_curve_target.rs), FqSqrtGenerator / Fq2SqrtGenerator roots and sgn0 (src/fields/helpers.rs:159-174).
+    Returns (point | None, flags); sgn & 2 = infinity."""
+    if sgn & 2:
+        return None, FLAG_INFINITY
+    if group == 1:
+        rhs = (pow(x, 3, P) + 4) % P
+        y, fl = witness_fq_sqrt(rhs, sgn)
+    else:
+        rhs = fp2_add(fp2_mul(fp2_sqr(x), x), (4, 4))
+        y, fl = witness_fq2_sqrt(rhs, sgn)
+    if fl & WFLAG_NOT_SQUARE:
+        return None, fl
+    return (x, y), fl
+
+
 def witness_fq2_inverse(x):
     """Fq2InverseGenerator::run_once, src/fields/fq2_target.rs:331-352: None -> zero."""
     r = fp2_inv((x[0] % P, x[1] % P))

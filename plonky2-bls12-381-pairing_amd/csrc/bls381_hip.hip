@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/bls381_hip.h"
 #include "launch.h"
@@ -43,6 +45,12 @@ struct bls381_ctx {
   hipEvent_t fork = nullptr, stagger[MAX_PIPES] = {}, join[MAX_PIPES] = {};
   hipStream_t scratch_stream = nullptr;
   bool scratch_used = false;
+  // host-pointer entry points: context-owned, grow-only device staging (kind: in1, in2, out, flags; two slots for the
+  // double-buffered pipeline), copy streams and the events that order copies against launches
+  void* stage_buf[4][2] = {};
+  size_t stage_cap[4][2] = {};
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  hipEvent_t in_ready[2] = {}, computed[2] = {}, out_copied[2] = {};
 };
 
 #define HIP_TRY(ctx, expr)                                        \
@@ -88,6 +96,12 @@ int bls381_create(bls381_ctx** out, int device_id) {
     bls381_destroy(c);
     return BLS381_E_NO_DEVICE;
   }
+  bool ok = hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < 2; ++i)
+    ok = hipEventCreateWithFlags(&c->in_ready[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->computed[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->out_copied[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { bls381_destroy(c); return BLS381_E_NO_DEVICE; }
   c->stream = c->own_stream;
   *out = c;
   return BLS381_OK;
@@ -110,6 +124,14 @@ void bls381_destroy(bls381_ctx* c) {
     if (c->stagger[i]) (void)hipEventDestroy(c->stagger[i]);
   }
   if (c->fork) (void)hipEventDestroy(c->fork);
+  for (int k = 0; k < 4; ++k) for (int i = 0; i < 2; ++i) if (c->stage_buf[k][i]) (void)hipFree(c->stage_buf[k][i]);
+  for (int i = 0; i < 2; ++i) {
+    if (c->in_ready[i]) (void)hipEventDestroy(c->in_ready[i]);
+    if (c->computed[i]) (void)hipEventDestroy(c->computed[i]);
+    if (c->out_copied[i]) (void)hipEventDestroy(c->out_copied[i]);
+  }
+  if (c->h2d) (void)hipStreamDestroy(c->h2d);
+  if (c->d2h) (void)hipStreamDestroy(c->d2h);
   delete c;
 }
 
@@ -355,20 +377,82 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
-// Stages host inputs to the device, runs `body` on device pointers, copies the outputs back.
+// Device staging of the host-pointer entry points: grow-only buffers owned by the context (no hipMalloc per call once warm).
+// Every host-pointer entry point ends with a synchronisation, so the buffers are idle whenever one starts.
+enum { ST_IN1 = 0, ST_IN2 = 1, ST_OUT = 2, ST_FLAGS = 3 };
+int stage_ensure(bls381_ctx* c, int kind, int slot, size_t bytes, void** p) {
+  *p = nullptr;
+  if (bytes == 0) return BLS381_OK;
+  if (c->stage_cap[kind][slot] < bytes) {
+    if (c->stage_buf[kind][slot]) { (void)hipFree(c->stage_buf[kind][slot]); c->stage_buf[kind][slot] = nullptr; c->stage_cap[kind][slot] = 0; }
+    HIP_TRY(c, hipMalloc(&c->stage_buf[kind][slot], bytes));
+    c->stage_cap[kind][slot] = bytes;
+  }
+  *p = c->stage_buf[kind][slot];
+  return BLS381_OK;
+}
+
+// Stages host inputs to the device, runs `body` on device pointers, copies the outputs back (one piece, for the small surfaces).
 template <class Body>
 int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* in2, size_t in2_bytes,
                  void* out, size_t out_bytes, uint8_t* flags, size_t n, Body body) {
   HIP_TRY(c, hipSetDevice(c->device));
-  DevBuf d1, d2, dout, dfl;
-  if (in1_bytes) { HIP_TRY(c, hipMalloc(&d1.p, in1_bytes)); HIP_TRY(c, hipMemcpyAsync(d1.p, in1, in1_bytes, hipMemcpyHostToDevice, c->stream)); }
-  if (in2 && in2_bytes) { HIP_TRY(c, hipMalloc(&d2.p, in2_bytes)); HIP_TRY(c, hipMemcpyAsync(d2.p, in2, in2_bytes, hipMemcpyHostToDevice, c->stream)); }
-  HIP_TRY(c, hipMalloc(&dout.p, out_bytes));
-  if (flags) HIP_TRY(c, hipMalloc(&dfl.p, n));
-  int rc = body((const uint64_t*)d1.p, (const uint64_t*)d2.p, (uint64_t*)dout.p, (uint8_t*)dfl.p);
+  void *d1, *d2, *dout, *dfl;
+  int rc;
+  if ((rc = stage_ensure(c, ST_IN1, 0, in1_bytes, &d1)) || (rc = stage_ensure(c, ST_IN2, 0, in2 ? in2_bytes : 0, &d2)) ||
+      (rc = stage_ensure(c, ST_OUT, 0, out_bytes, &dout)) || (rc = stage_ensure(c, ST_FLAGS, 0, flags ? n : 0, &dfl))) return rc;
+  if (d1) HIP_TRY(c, hipMemcpyAsync(d1, in1, in1_bytes, hipMemcpyHostToDevice, c->stream));
+  if (d2) HIP_TRY(c, hipMemcpyAsync(d2, in2, in2_bytes, hipMemcpyHostToDevice, c->stream));
+  rc = body((const uint64_t*)d1, (const uint64_t*)d2, (uint64_t*)dout, (uint8_t*)dfl);
   if (rc != BLS381_OK) return rc;
-  HIP_TRY(c, hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
-  if (flags) HIP_TRY(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (flags) HIP_TRY(c, hipMemcpyAsync(flags, dfl, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BLS381_OK;
+}
+
+// The pairing-sized entry points: the batch moves in pieces of STAGE_PIECE elements through two device slots, copies on their own
+// streams, so that the upload of piece i+1 and the download of piece i-1 run under the kernels of piece i.  What stays exposed is
+// the first upload and the last download.  A piece is large enough for the staged final exponentiation (2^19 elements).
+// w1 / w2 / wo: bytes per element of the two inputs and of the output; body(in1, in2, out, flags, first, m) queues m elements on c->stream.
+constexpr size_t STAGE_PIECE = (size_t)1 << 19;
+template <class Body>
+int staged_pipeline(bls381_ctx* c, const void* in1, size_t w1, const void* in2, size_t w2, void* out, size_t wo, uint8_t* flags, size_t n, Body body) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t piece = (n <= STAGE_PIECE + STAGE_PIECE / 2) ? n : STAGE_PIECE;
+  const size_t pieces = (n + piece - 1) / piece;
+  const int slots = pieces > 1 ? 2 : 1;
+  void *d1[2] = {}, *d2[2] = {}, *dout[2] = {}, *dfl[2] = {};
+  for (int sl = 0; sl < slots; ++sl) {
+    int rc;
+    if ((rc = stage_ensure(c, ST_IN1, sl, piece * w1, &d1[sl])) || (rc = stage_ensure(c, ST_IN2, sl, in2 ? piece * w2 : 0, &d2[sl])) ||
+        (rc = stage_ensure(c, ST_OUT, sl, piece * wo, &dout[sl])) || (rc = stage_ensure(c, ST_FLAGS, sl, flags ? piece : 0, &dfl[sl]))) return rc;
+  }
+  auto download = [&](size_t i) -> int {
+    const int sl = (int)(i & 1);
+    const size_t first = i * piece, m = (n - first < piece) ? n - first : piece;
+    HIP_TRY(c, hipStreamWaitEvent(c->d2h, c->computed[sl], 0));
+    HIP_TRY(c, hipMemcpyAsync((char*)out + first * wo, dout[sl], m * wo, hipMemcpyDeviceToHost, c->d2h));
+    if (flags) HIP_TRY(c, hipMemcpyAsync(flags + first, dfl[sl], m, hipMemcpyDeviceToHost, c->d2h));
+    HIP_TRY(c, hipEventRecord(c->out_copied[sl], c->d2h));
+    return BLS381_OK;
+  };
+  for (size_t i = 0; i < pieces; ++i) {
+    const int sl = (int)(i & 1);
+    const size_t first = i * piece, m = (n - first < piece) ? n - first : piece;
+    if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->h2d, c->computed[sl], 0));        // the kernels of piece i-2 have read this slot
+    if (d1[sl]) HIP_TRY(c, hipMemcpyAsync(d1[sl], (const char*)in1 + first * w1, m * w1, hipMemcpyHostToDevice, c->h2d));
+    if (d2[sl]) HIP_TRY(c, hipMemcpyAsync(d2[sl], (const char*)in2 + first * w2, m * w2, hipMemcpyHostToDevice, c->h2d));
+    HIP_TRY(c, hipEventRecord(c->in_ready[sl], c->h2d));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_ready[sl], 0));
+    if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->out_copied[sl], 0));    // piece i-2 has left the output slot
+    const int rc = body((const uint64_t*)d1[sl], (const uint64_t*)d2[sl], (uint64_t*)dout[sl], (uint8_t*)dfl[sl], first, m);
+    if (rc != BLS381_OK) { (void)hipDeviceSynchronize(); return rc; }
+    HIP_TRY(c, hipEventRecord(c->computed[sl], c->stream));
+    if (i >= 1) { const int r2 = download(i - 1); if (r2 != BLS381_OK) return r2; }   // blocks the host at most until piece i-1 is computed; piece i is queued
+  }
+  { const int r2 = download(pieces - 1); if (r2 != BLS381_OK) return r2; }
+  HIP_TRY(c, hipStreamSynchronize(c->d2h));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BLS381_OK;
 }
@@ -385,8 +469,8 @@ int bls381_miller_ref_opt_batch_dev(bls381_ctx* c, const uint64_t* g1, const uin
 int bls381_miller_ref_opt_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
   if (!c || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
-  return with_staging(c, g1, n * 144, g2, n * 288, out, n * 576, flags, n,
-                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_ref_opt(c, a, b, o, f, n); });
+  return staged_pipeline(c, g1, 144, g2, 288, out, 576, flags, n,
+                         [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f, size_t, size_t m) { return launch_ref_opt(c, a, b, o, f, m); });
 }
 
 int bls381_multi_miller_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
@@ -402,15 +486,15 @@ int bls381_multi_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint
 int bls381_multi_miller_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
   if (!c || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
-  return with_staging(c, g1, n * k * 96, g2, n * k * 192, out, n * 576, flags, n,
-                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_multi<false>(c, a, b, k, o, f, n); });
+  return staged_pipeline(c, g1, k * 96, g2, k * 192, out, 576, flags, n,
+                         [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f, size_t, size_t m) { return launch_multi<false>(c, a, b, k, o, f, m); });
 }
 
 int bls381_multi_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
   if (!c || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
-  return with_staging(c, g1, n * k * 96, g2, n * k * 192, out, n * 576, flags, n,
-                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) { return launch_multi<true>(c, a, b, k, o, f, n); });
+  return staged_pipeline(c, g1, k * 96, g2, k * 192, out, 576, flags, n,
+                         [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f, size_t, size_t m) { return launch_multi<true>(c, a, b, k, o, f, m); });
 }
 
 int bls381_miller_ate_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
@@ -429,8 +513,8 @@ int bls381_final_exp_batch_dev(bls381_ctx* c, const uint64_t* in, uint64_t* out,
 int bls381_final_exp_batch(bls381_ctx* c, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
   if (!c || (n && (!in || !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
-  return with_staging(c, in, n * 576, nullptr, 0, out, n * 576, flags, n,
-                      [&](const uint64_t* a, const uint64_t*, uint64_t* o, uint8_t* f) { return launch_final_exp(c, a, o, f, n); });
+  return staged_pipeline(c, in, 576, nullptr, 0, out, 576, flags, n,
+                         [&](const uint64_t* a, const uint64_t*, uint64_t* o, uint8_t* f, size_t, size_t m) { return launch_final_exp(c, a, o, f, m); });
 }
 
 int bls381_fp_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
@@ -525,10 +609,10 @@ int bls381_prepared_pairing_batch(bls381_ctx* c, const uint64_t* g1_aff, const u
   const size_t prep_bytes = n_fixed * 68 * 288;
   HIP_TRY(c, hipMalloc(&dprep.p, prep_bytes));
   HIP_TRY(c, hipMemcpyAsync(dprep.p, prepared_fixed, prep_bytes, hipMemcpyHostToDevice, c->stream));
-  return with_staging(c, g1_aff, n * (n_var + n_fixed) * 96, n_var ? g2_var : nullptr, n_var ? n * 192 : 0, out_gt, n * 576, flags, n,
-                      [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f) -> int {
-                        return bls381_prepared_pairing_batch_dev(c, a, b, (const uint64_t*)dprep.p, n_var, n_fixed, o, f, n);
-                      });
+  return staged_pipeline(c, g1_aff, (n_var + n_fixed) * 96, n_var ? g2_var : nullptr, n_var ? 192 : 0, out_gt, 576, flags, n,
+                         [&](const uint64_t* a, const uint64_t* b, uint64_t* o, uint8_t* f, size_t, size_t m) -> int {
+                           return bls381_prepared_pairing_batch_dev(c, a, b, (const uint64_t*)dprep.p, n_var, n_fixed, o, f, m);
+                         });
 }
 
 int bls381_groth16_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
@@ -566,8 +650,8 @@ int bls381_g2_prepare_batch(bls381_ctx* c, const uint64_t* g2_aff, uint64_t* coe
 // ---- point surface (G1 / G2 Jacobian points)
 static int point_op(bls381_ctx* c, int group, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n) {
   const bool binary = op == BLS381_POINT_ADD || op == BLS381_POINT_EQ;
-  const bool predicate = op == BLS381_POINT_EQ || op == BLS381_POINT_IS_ON_CURVE;
-  if (!c || op < BLS381_POINT_ADD || op > BLS381_POINT_IS_ON_CURVE) return BLS381_E_INVALID;
+  const bool predicate = op == BLS381_POINT_EQ || op == BLS381_POINT_IS_ON_CURVE || op == BLS381_POINT_IS_IN_SUBGROUP;
+  if (!c || op < BLS381_POINT_ADD || op > BLS381_POINT_IS_IN_SUBGROUP) return BLS381_E_INVALID;
   if (n && (!a || (binary && !b) || (predicate ? !flags : !out))) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   const size_t bytes = n * (group == 1 ? 144 : 288);
@@ -592,6 +676,25 @@ int bls381_g1_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t*
 }
 int bls381_g2_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n) {
   return point_op(c, 2, op, a, b, out, flags, n);
+}
+
+// ---- point decompression
+static int decompress(bls381_ctx* c, int group, const uint64_t* x, const uint8_t* sign, uint64_t* out_aff, uint8_t* flags, size_t n) {
+  if (!c || (n && (!x || !sign || !out_aff))) return BLS381_E_INVALID;
+  if (n == 0) return BLS381_OK;
+  const size_t w = group == 1 ? 48 : 96;
+  return with_staging(c, x, n * w, sign, n, out_aff, n * 2 * w, flags, n,
+                      [&](const uint64_t* dx, const uint64_t* dsgn, uint64_t* o, uint8_t* f) -> int {
+                        bls_launch::decompress(group, dx, (const uint8_t*)dsgn, o, f, n, c->io_form, c->block, c->stream);
+                        HIP_TRY(c, hipGetLastError());
+                        return (int)BLS381_OK;
+                      });
+}
+int bls381_g1_decompress_batch(bls381_ctx* c, const uint64_t* x, const uint8_t* sign, uint64_t* out_aff, uint8_t* flags, size_t n) {
+  return decompress(c, 1, x, sign, out_aff, flags, n);
+}
+int bls381_g2_decompress_batch(bls381_ctx* c, const uint64_t* x, const uint8_t* sign, uint64_t* out_aff, uint8_t* flags, size_t n) {
+  return decompress(c, 2, x, sign, out_aff, flags, n);
 }
 
 // ---- witness-generator backend (canonical 12 x u32 digits == 6 x u64 per Fp)
@@ -660,6 +763,96 @@ int bls381_multi_miller_literal(bls381_ctx* c, uint64_t* out, size_t n) {
                         HIP_TRY(c, hipGetLastError());
                         return (int)BLS381_OK;
                       });
+}
+
+// ------------------------------------------------------------------------------------------ several devices, one host process
+// SURVEY 8e for a host that is ONE process (the reference's caller is a single Rust program): one context per device, the batch cut
+// into contiguous ranges [g n / G, (g+1) n / G), every range through its device's host-pointer entry point (pinned-speed copies on
+// the context's copy streams, kernels on its own stream) from its own host thread.  Elements are independent: nothing is exchanged.
+struct bls381_multi {
+  std::vector<bls381_ctx*> ctx;
+};
+
+int bls381_create_multi(bls381_multi** out, const int* device_ids, int n_devices) {
+  if (!out) return BLS381_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BLS381_E_NO_DEVICE;
+  std::vector<int> ids;
+  if (!device_ids || n_devices <= 0) { for (int i = 0; i < count; ++i) ids.push_back(i); }
+  else ids.assign(device_ids, device_ids + n_devices);
+  bls381_multi* m = new (std::nothrow) bls381_multi();
+  if (!m) return BLS381_E_NOMEM;
+  for (int id : ids) {
+    bls381_ctx* c = nullptr;
+    const int rc = bls381_create(&c, id);
+    if (rc != BLS381_OK) { bls381_destroy_multi(m); return rc; }
+    m->ctx.push_back(c);
+  }
+  *out = m;
+  return BLS381_OK;
+}
+
+void bls381_destroy_multi(bls381_multi* m) {
+  if (!m) return;
+  for (bls381_ctx* c : m->ctx) bls381_destroy(c);
+  delete m;
+}
+
+int bls381_multi_device_count(const bls381_multi* m) { return m ? (int)m->ctx.size() : 0; }
+
+bls381_ctx* bls381_multi_context(bls381_multi* m, int index) {
+  return (m && index >= 0 && index < (int)m->ctx.size()) ? m->ctx[index] : nullptr;
+}
+
+int bls381_multi_set_option(bls381_multi* m, int option, int value) {
+  if (!m) return BLS381_E_INVALID;
+  for (bls381_ctx* c : m->ctx) { const int rc = bls381_set_option(c, option, value); if (rc != BLS381_OK) return rc; }
+  return BLS381_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// run(ctx, first, count) on every device's contiguous range, one host thread per device; the first error wins
+template <class Run>
+int sharded(bls381_multi* m, size_t n, Run run) {
+  const size_t G = m->ctx.size();
+  std::vector<int> rc(G, BLS381_OK);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; ++g) {
+    const size_t lo = n * g / G, hi = n * (g + 1) / G;
+    if (hi == lo) continue;
+    if (G == 1) rc[g] = run(m->ctx[g], lo, hi - lo);
+    else th.emplace_back([&, g, lo, hi] { rc[g] = run(m->ctx[g], lo, hi - lo); });
+  }
+  for (auto& t : th) t.join();
+  for (int r : rc) if (r != BLS381_OK) return r;
+  return BLS381_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int bls381_multi_pairing_batch_sharded(bls381_multi* m, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!m || m->ctx.empty() || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  return sharded(m, n, [&](bls381_ctx* c, size_t first, size_t cnt) {
+    return bls381_multi_pairing_batch(c, g1 + 12 * k * first, g2 + 24 * k * first, k, out + 72 * first, flags ? flags + first : nullptr, cnt);
+  });
+}
+
+int bls381_multi_miller_batch_sharded(bls381_multi* m, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!m || m->ctx.empty() || k < 1 || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  return sharded(m, n, [&](bls381_ctx* c, size_t first, size_t cnt) {
+    return bls381_multi_miller_batch(c, g1 + 12 * k * first, g2 + 24 * k * first, k, out + 72 * first, flags ? flags + first : nullptr, cnt);
+  });
+}
+
+int bls381_miller_ref_opt_batch_sharded(bls381_multi* m, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  if (!m || m->ctx.empty() || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
+  return sharded(m, n, [&](bls381_ctx* c, size_t first, size_t cnt) {
+    return bls381_miller_ref_opt_batch(c, g1 + 18 * first, g2 + 36 * first, out + 72 * first, flags ? flags + first : nullptr, cnt);
+  });
 }
 
 }  // extern "C"

@@ -30,8 +30,30 @@ struct Fp12C { Fp2R z2, z3, z4, z5; };       // compressed cyclotomic element
 
 BLS_HD Fp12C compress(const Fp12R& f) { return Fp12C{f.c1.c0, f.c0.c2, f.c0.c1, f.c1.c2}; }
 
-// the z2..z5 half of cyclotomic_square (tower.cuh), verbatim
+// The z2..z5 half of cyclotomic_square (tower.cuh).  Two forms with the same values:
+//   BLS_CSQR_PRODUCTS = 0   verbatim: two Fp4 squarings = six Fp2 squarings
+//   BLS_CSQR_PRODUCTS = 1   z2^2 + xi z3^2 = (z2 + z3)(z2 + xi z3) - (1 + xi) z2 z3  and  2 z2 z3 from the same product:
+//                           four Fp2 multiplications.  Per lane the multiply-add count is the same (4 x 588 = 6 x 392), but
+//                           four operand exchanges and four reductions replace six.
+#ifndef BLS_CSQR_PRODUCTS
+#define BLS_CSQR_PRODUCTS 1
+#endif
 BLS_HD Fp12C compressed_square(const Fp12C& g) {
+#if BLS_CSQR_PRODUCTS
+  const Fp2R b23 = mul(g.z2, g.z3), b45 = mul(g.z4, g.z5);
+  const Fp2R a23 = mul(add(g.z2, g.z3), add(g.z2, mul_xi(g.z3)));
+  const Fp2R a45 = mul(add(g.z4, g.z5), add(g.z4, mul_xi(g.z5)));
+  const auto xb23 = mul_xi(b23), xb45 = mul_xi(b45);
+  const auto ba = sub(a23, add(b23, xb23));                 // z2^2 + xi z3^2          (fp4_square(z2, z3).a)
+  const auto ca = sub(a45, add(b45, xb45));                 // z4^2 + xi z5^2          (fp4_square(z4, z5).a)
+  const auto n4 = sub(add(dbl(ba), ba), dbl(g.z4));         // 3 B.a - 2 z4
+  const auto n3 = sub(add(dbl(ca), ca), dbl(g.z3));         // 3 C.a - 2 z3
+  const auto b23x2 = dbl(b23);
+  const auto n5 = dbl(add(add(b23x2, b23), g.z5));          // 3 (2 z2 z3) + 2 z5
+  const auto xb45x2 = dbl(fit<1, 8>(xb45));
+  const auto n2 = dbl(add(add(xb45x2, fit<1, 8>(xb45)), g.z2));   // 3 xi (2 z4 z5) + 2 z2
+  return Fp12C{fit<1, 2>(n2), fit<1, 2>(n3), fit<1, 2>(n4), fit<1, 2>(n5)};
+#else
   const auto B = fp4_square(g.z2, g.z3);
   const auto C = fp4_square(g.z4, g.z5);
   const auto n4 = add(dbl(sub(B.a, g.z4)), B.a);
@@ -40,6 +62,7 @@ BLS_HD Fp12C compressed_square(const Fp12C& g) {
   const auto n2 = add(dbl(add(t0, g.z2)), t0);
   const auto n3 = add(dbl(sub(C.a, g.z3)), C.a);
   return Fp12C{fit<1, 2>(n2), fit<1, 2>(n3), fit<1, 2>(n4), fit<1, 2>(n5)};
+#endif
 }
 
 // denominator of z1 (4 z2, or z3 when z2 = 0) with zero replaced by one, and whether it was zero: then z1 = 0, which
@@ -124,7 +147,7 @@ BLS_HD_NOINLINE void fexp_start_exp(const Fp12R& x, const FexpScratch& sc) {
 }
 
 // second half: conj(x^|x|) from the parked powers and the inverse of the norm (== cyclotomic_exp(x), tower.cuh)
-BLS_HD_NOINLINE Fp12R fexp_finish_exp(const FexpScratch& sc) {
+BLS_FN_COLD Fp12R fexp_finish_exp(const FexpScratch& sc) {
   const FpR norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
   // inverse of the product of all six denominators; peel one denominator per step, last power first
   Fp2R prod = fp2_scratch_get(sc.ls, FX_PRE_BASE + 5);

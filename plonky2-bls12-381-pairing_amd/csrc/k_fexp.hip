@@ -3,6 +3,7 @@
 // with a 512-register kernel would be compiled for 512 registers and drag this kernel back to one wave per SIMD.
 // Here every kernel asks for two waves per SIMD, so the routines are compiled for 256 registers.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "../../include/bls381_hip.h"
 #include "pairing.cuh"
 #include "fexp_stages.cuh"
@@ -114,7 +115,9 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
     after(4);
     fp_batch_inv_raw(raw_scratch, m, s);
     before(5);
-    hipLaunchKernelGGL(k_fexp_stage<6>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    static const bool narrow6 = getenv("BLS381_NARROW_STAGE6") != nullptr;      // A/B switch (tools/collect_profile.sh)
+    if (narrow6) hipLaunchKernelGGL(k_fexp_stage<6>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
+    else fexp_stage6_wide(co, cf, stage_scratch, raw_scratch, m, lanes, form, block, s);
     after(5);
   }
 }

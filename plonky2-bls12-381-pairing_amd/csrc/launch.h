@@ -25,6 +25,8 @@ size_t fexp_stage_scratch_bytes(size_t n_chunk);
 void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
                       uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
                       const hipEvent_t* wait_before, const hipEvent_t* record_after);
+// stage 6 of the staged form compiled for one wave per SIMD (k_fexp_wide.hip); same arguments as the stage kernels
+void fexp_stage6_wide(uint64_t* out, uint8_t* flags, uint32_t* scratch, uint32_t* norm_raw, size_t n, size_t lanes, int form, int block, hipStream_t s);
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp6_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
@@ -38,5 +40,7 @@ bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, 
 void fp_pow(const uint64_t* a, const uint64_t* exp, int nwords, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void g2_prepare(const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void witness_inverse(int op, const uint64_t* x, uint64_t* out, uint8_t* flags, size_t n, int block, hipStream_t s);
+// group 1: x n x 6 u64 -> out n x 12; group 2: x n x 12 -> out n x 24; sgn: n bytes (bit 0 sign of y, bit 1 infinity)
+void decompress(int group, const uint64_t* x, const uint8_t* sgn, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void witness_sqrt(int op, const uint64_t* x, const uint8_t* sgn, uint64_t* out, uint8_t* flags, size_t n, int block, hipStream_t s);
 }  // namespace bls_launch

@@ -117,7 +117,9 @@ BLS_HD_NOINLINE G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) { return jac_
 
 // Point helpers around the pairing (the reference's curve types: src/fields_as_trees/g2_curve.rs:29-166,
 // g1_curve.rs:22-110; arkworks `Projective` equality / normalisation [third party]).
-enum : int { POINT_ADD = 0, POINT_DOUBLE = 1, POINT_NORMALIZE = 2, POINT_EQ = 3, POINT_ON_CURVE = 4 };
+enum : int { POINT_ADD = 0, POINT_DOUBLE = 1, POINT_NORMALIZE = 2, POINT_EQ = 3, POINT_ON_CURVE = 4, POINT_IN_SUBGROUP = 5 };
+// group order r (KAT-6: the decimal at src/miller_loop_native_optimized.rs:110), little-endian u64 words
+BLS_CONST uint64_t BLS_R_ORDER[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
 enum : uint8_t { FLAG_TRUE = 32 };
 
 // `Projective == Projective`: both at infinity, or neither and X1 Z2^2 == X2 Z1^2, Y1 Z2^3 == Y2 Z1^3
@@ -135,6 +137,19 @@ BLS_HD bool jac_on_curve(const Jac<F>& a) {
   const F z2 = fsqr(a.z);
   const F z6 = fmul(fsqr(z2), z2);
   return eq(fsqr(a.y), add(fmul(fsqr(a.x), a.x), mul_curve_b(z6)));
+}
+// [r] a == infinity for a point ON the curve: membership in the order-r subgroup (what arkworks' `G1Affine` / `G2Affine`
+// deserialisation checks, `is_in_correct_subgroup_assuming_on_curve` [third party]); plain MSB-first double-and-add with the
+// group law above, r is a constant so control flow is uniform.  The point at infinity is a member.
+template <class F>
+BLS_HD_NOINLINE bool jac_in_subgroup(const Jac<F>& a) {
+  if (!jac_on_curve(a)) return false;
+  Jac<F> acc = a;                                   // leading one bit of r (bit 254)
+  for (int b = 253; b >= 0; --b) {
+    acc = jac_double_call(acc);
+    if ((BLS_R_ORDER[b >> 6] >> (b & 63)) & 1ull) acc = jac_add(acc, a);
+  }
+  return is_zero(acc.z);
 }
 // the representative with Z = 1 (`Affine::from(Projective)` followed by `Projective::from`); infinity -> (1, 1, 0),
 // arkworks' `Projective::zero()`
@@ -159,6 +174,7 @@ BLS_HD uint8_t point_op(int op, const Jac<F>& a, const Jac<F>& b, Jac<F>& r) {
     case POINT_NORMALIZE: r = jac_normalize(a); break;
     case POINT_EQ: r = a; pred = jac_eq(a, b); break;
     case POINT_ON_CURVE: r = a; pred = jac_on_curve(a); break;
+    case POINT_IN_SUBGROUP: r = a; pred = jac_in_subgroup(a); break;
     default: r = a; break;
   }
   return (uint8_t)((is_zero(r.z) ? FLAG_INFINITY : 0) | (pred ? FLAG_TRUE : 0));

@@ -42,6 +42,17 @@
 #else
 #define BLS_FN_FP12 BLS_HD_NOINLINE
 #endif
+// The *_call wrappers of cold glue: real functions by default (one shared copy; arguments and results travel through the
+// stack, i.e. scratch).  A translation unit compiled for one wave per SIMD can afford to inline them (BLS_COLD_INLINE=1): the
+// Fq12 values then stay in registers (k_fexp_wide.hip).
+#ifndef BLS_COLD_INLINE
+#define BLS_COLD_INLINE 0
+#endif
+#if BLS_COLD_INLINE
+#define BLS_FN_COLD BLS_HD
+#else
+#define BLS_FN_COLD BLS_HD_NOINLINE
+#endif
 
 namespace bls {
 
@@ -260,9 +271,9 @@ BLS_FN_FP12 Fp12R mul_by_014(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const F
 
 // Out-of-line entry points for cold call sites (final-exponentiation glue, reference-mode accumulators): one
 // shared copy of each routine however BLS_FN_FP12 is set.
-BLS_HD_NOINLINE Fp12R mul_call(const Fp12R& a, const Fp12R& b) { return mul(a, b); }
-BLS_HD_NOINLINE Fp12R sqr_call(const Fp12R& a) { return sqr(a); }
-BLS_HD_NOINLINE Fp12R frobenius_call(const Fp12R& a) { return frobenius(a); }
+BLS_FN_COLD Fp12R mul_call(const Fp12R& a, const Fp12R& b) { return mul(a, b); }
+BLS_FN_COLD Fp12R sqr_call(const Fp12R& a) { return sqr(a); }
+BLS_FN_COLD Fp12R frobenius_call(const Fp12R& a) { return frobenius(a); }
 
 // ---- cyclotomic subgroup (final exponentiation)   -- src/fields_as_trees/miller_loop.rs:29-126
 template <class A, class B> struct Pair2 { A a; B b; };
@@ -297,7 +308,7 @@ BLS_FN_FP12 Fp12R cyclotomic_square(const Fp12<L, V>& f) {
                Fp6R(fit<1, 2>(n2), fit<1, 2>(n1), fit<1, 2>(n5)));
 }
 
-BLS_HD_NOINLINE Fp12R cyclotomic_square_call(const Fp12R& a) { return cyclotomic_square(a); }
+BLS_FN_COLD Fp12R cyclotomic_square_call(const Fp12R& a) { return cyclotomic_square(a); }
 
 // conj(f^|x|), MSB-first square-and-multiply over BLS_X   -- miller_loop.rs:106-126, with the product the
 // reference drops at :121 kept.

@@ -110,4 +110,13 @@ BLS_HD Fp2R witness_fq2_sqrt(const Fp2R& x, bool sgn, uint8_t& flags) {
   return Fp2R(fp2_from_coeffs(o0, o1));
 }
 
+// Point decompression: the affine point with abscissa x whose ordinate has the requested sign, built from the
+// reference's own pieces -- the curve equations y^2 = x^3 + 4 / y^2 = x^3 + 4 (1 + u) (src/curves/g1_curve_target.rs,
+// g2_curve_target.rs), the square roots above and sgn0_fq / sgn0_fq2 (src/fields/helpers.rs:159-174).  y = 0 does not occur:
+// both group orders are odd, so neither curve has a point of order two.
+BLS_HD FpR curve_rhs(const FpR& x) { return fit<1, 2>(add(mul(sqr(x), x), dbl(dbl(fp_one())))); }
+BLS_HD Fp2R curve_rhs(const Fp2R& x) { return fit<1, 2>(add(mul(sqr(x), x), dbl(dbl(mul_xi(fp2_one()))))); }
+BLS_HD FpR decompress_y(const FpR& x, bool sgn, uint8_t& flags) { return witness_fq_sqrt(curve_rhs(x), sgn, flags); }
+BLS_HD Fp2R decompress_y(const Fp2R& x, bool sgn, uint8_t& flags) { return witness_fq2_sqrt(curve_rhs(x), sgn, flags); }
+
 }  // namespace bls

@@ -23,7 +23,7 @@ OPT_FEXP_CHUNK_LOG2 = 6
 FEXP_SELF_CONTAINED, FEXP_BATCHED_INVERSION, FEXP_STAGED, FEXP_AUTO = 0, 1, 2, 3
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_TRUE = 32
-POINT_ADD, POINT_DOUBLE, POINT_NORMALIZE, POINT_EQ, POINT_IS_ON_CURVE = range(5)
+POINT_ADD, POINT_DOUBLE, POINT_NORMALIZE, POINT_EQ, POINT_IS_ON_CURVE, POINT_IS_IN_SUBGROUP = range(6)
 FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
 FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV, FP_LEGENDRE, FP_IS_SQUARE, FP_SGN0 = range(12)
 FP2_ADD, FP2_SUB, FP2_MUL, FP2_SQR, FP2_INV, FP2_NEG, FP2_CONJ, FP2_MUL_BY_NONRESIDUE = range(8)
@@ -46,7 +46,9 @@ SYMBOLS = [
     "bls381_fq12_ark_to_myfq12", "bls381_fq12_myfq12_to_ark",
     "bls381_witness_fq12_inverse_batch", "bls381_witness_fq6_inverse_batch", "bls381_witness_fq2_inverse_batch",
     "bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch",
-    "bls381_g1_op_batch", "bls381_g2_op_batch",
+    "bls381_g1_op_batch", "bls381_g2_op_batch", "bls381_g1_decompress_batch", "bls381_g2_decompress_batch",
+    "bls381_create_multi", "bls381_destroy_multi", "bls381_multi_device_count", "bls381_multi_context", "bls381_multi_set_option",
+    "bls381_multi_pairing_batch_sharded", "bls381_multi_miller_batch_sharded", "bls381_miller_ref_opt_batch_sharded",
 ]
 
 
@@ -99,6 +101,18 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         getattr(lib, name).argtypes = [vp, u32p, u32p, u8p, sz]
     for name in ("bls381_witness_fq_sqrt_batch", "bls381_witness_fq2_sqrt_batch"):
         getattr(lib, name).argtypes = [vp, u32p, u8p, u32p, u8p, sz]
+    lib.bls381_g1_decompress_batch.argtypes = [vp, u64p, u8p, u64p, u8p, sz]
+    lib.bls381_g2_decompress_batch.argtypes = [vp, u64p, u8p, u64p, u8p, sz]
+    lib.bls381_create_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.bls381_destroy_multi.argtypes = [vp]
+    lib.bls381_destroy_multi.restype = None
+    lib.bls381_multi_device_count.argtypes = [vp]
+    lib.bls381_multi_context.argtypes = [vp, ctypes.c_int]
+    lib.bls381_multi_context.restype = vp
+    lib.bls381_multi_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.bls381_multi_pairing_batch_sharded.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
+    lib.bls381_multi_miller_batch_sharded.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
+    lib.bls381_miller_ref_opt_batch_sharded.argtypes = [vp, u64p, u64p, u64p, u8p, sz]
     # device-pointer twins take raw addresses
     lib.bls381_miller_ref_opt_batch_dev.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.bls381_multi_miller_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
@@ -110,6 +124,64 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
 def _u64(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+class MultiEngine:
+    """Several devices behind one process (`bls381_multi`): contiguous ranges of the batch, one per device."""
+
+    def __init__(self, device_ids=None, lib_path: str = LIB_PATH):
+        self.lib = load_library(lib_path)
+        self._m = ctypes.c_void_p()
+        ids = None
+        if device_ids is not None:
+            ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        rc = self.lib.bls381_create_multi(ctypes.byref(self._m), ids, 0 if device_ids is None else len(device_ids))
+        if rc != 0:
+            raise Bls381Error(f"bls381_create_multi({device_ids}): {self.lib.bls381_strerror(rc).decode()}")
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self.lib.bls381_destroy_multi(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_count(self):
+        return self.lib.bls381_multi_device_count(self._m)
+
+    def set_option(self, opt, value):
+        rc = self.lib.bls381_multi_set_option(self._m, opt, value)
+        if rc != 0:
+            raise Bls381Error("bls381_multi_set_option: " + self.lib.bls381_strerror(rc).decode())
+
+    def _run(self, fn, name, a, b, w1, w2, k=None, out=None):
+        a, pa = _u64(a)
+        b, pb = _u64(b)
+        n = a.size // w1
+        assert a.size == n * w1 and b.size == n * w2, "ragged input"
+        if out is None:
+            out = np.empty(n * 72, dtype=np.uint64)
+        assert out.size == n * 72 and out.dtype == np.uint64 and out.flags.c_contiguous
+        flags = np.zeros(n, dtype=np.uint8)
+        po, pf = out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        rc = fn(self._m, pa, pb, po, pf, n) if k is None else fn(self._m, pa, pb, k, po, pf, n)
+        if rc != 0:
+            raise Bls381Error(f"{name}: {self.lib.bls381_strerror(rc).decode()}")
+        return out, flags
+
+    def multi_pairing(self, g1_aff, g2_aff, k=1, out=None):
+        return self._run(self.lib.bls381_multi_pairing_batch_sharded, "bls381_multi_pairing_batch_sharded", g1_aff, g2_aff, 12 * k, 24 * k, k, out)
+
+    def multi_miller_loop(self, g1_aff, g2_aff, k=1, out=None):
+        return self._run(self.lib.bls381_multi_miller_batch_sharded, "bls381_multi_miller_batch_sharded", g1_aff, g2_aff, 12 * k, 24 * k, k, out)
+
+    def optimized_miller_loop(self, g1_jac, g2_jac, out=None):
+        return self._run(self.lib.bls381_miller_ref_opt_batch_sharded, "bls381_miller_ref_opt_batch_sharded", g1_jac, g2_jac, 18, 36, None, out)
 
 
 class Engine:
@@ -175,12 +247,14 @@ class Engine:
                     "bls381_miller_ref_opt_batch")
         return out, flags
 
-    def _multi(self, fn, name, g1_aff, g2_aff, k):
+    def _multi(self, fn, name, g1_aff, g2_aff, k, out=None):
         a, pa = _u64(g1_aff)
         b, pb = _u64(g2_aff)
         n = a.size // (12 * k)
         assert a.size == n * 12 * k and b.size == n * 24 * k, "ragged input"
-        out = np.zeros(n * 72, dtype=np.uint64)
+        if out is None:
+            out = np.zeros(n * 72, dtype=np.uint64)
+        assert out.size == n * 72 and out.dtype == np.uint64 and out.flags.c_contiguous
         flags = np.zeros(n, dtype=np.uint8)
         self._check(fn(self._ctx, pa, pb, k, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                        flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), name)
@@ -191,8 +265,9 @@ class Engine:
         n products of k Miller loops each."""
         return self._multi(self.lib.bls381_multi_miller_batch, "bls381_multi_miller_batch", g1_aff, g2_aff, k)
 
-    def multi_pairing(self, g1_aff, g2_aff, k=1):
-        return self._multi(self.lib.bls381_multi_pairing_batch, "bls381_multi_pairing_batch", g1_aff, g2_aff, k)
+    def multi_pairing(self, g1_aff, g2_aff, k=1, out=None):
+        """n products of k pairings; `out` (n*72 u64) lets a caller reuse its result buffer like a Rust caller reuses a Vec."""
+        return self._multi(self.lib.bls381_multi_pairing_batch, "bls381_multi_pairing_batch", g1_aff, g2_aff, k, out)
 
     def final_exponentiation(self, f):
         a, pa = _u64(f)
@@ -316,12 +391,28 @@ class Engine:
         if b is not None:
             b, pb = _u64(b)
             assert b.size == a.size
-        predicate = op in (POINT_EQ, POINT_IS_ON_CURVE)
+        predicate = op in (POINT_EQ, POINT_IS_ON_CURVE, POINT_IS_IN_SUBGROUP)
         out = None if predicate else np.zeros(n * w, dtype=np.uint64)
         flags = np.zeros(n, dtype=np.uint8)
         fn = self.lib.bls381_g1_op_batch if group == 1 else self.lib.bls381_g2_op_batch
         self._check(fn(self._ctx, op, pa, pb, None if predicate else out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                        flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n), "bls381_g%d_op_batch" % group)
+        return out, flags
+
+    def decompress(self, group, x, sign):
+        """bls381_g1_decompress_batch (group 1: x n*6 u64) / bls381_g2_decompress_batch (group 2: x n*12 u64): the affine point
+        with abscissa x whose ordinate has sgn0 == sign & 1 (sign & 2: infinity).  Returns (points n*12 / n*24 u64, flags)."""
+        w = 6 if group == 1 else 12
+        x, px = _u64(x)
+        n = x.size // w
+        sign = np.ascontiguousarray(sign, dtype=np.uint8)
+        assert x.size == n * w and sign.size == n, "ragged input"
+        out = np.zeros(n * 2 * w, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.bls381_g1_decompress_batch if group == 1 else self.lib.bls381_g2_decompress_batch
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        self._check(fn(self._ctx, px, sign.ctypes.data_as(u8p), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), flags.ctypes.data_as(u8p), n),
+                    "bls381_g%d_decompress_batch" % group)
         return out, flags
 
     def line_ref_opt(self, q1_jac, q2_jac, p_jac):

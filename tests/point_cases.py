@@ -6,7 +6,7 @@ import random
 
 from blsutil import O, enc_fps, dec_fps, point_pool, rand_fp
 
-ADD, DOUBLE, NORMALIZE, EQ, ON_CURVE = range(5)
+ADD, DOUBLE, NORMALIZE, EQ, ON_CURVE, IN_SUBGROUP = range(6)
 FLAG_INFINITY, FLAG_TRUE = 2, 32
 
 
@@ -41,12 +41,29 @@ def build(group, seed=2024):
     b = [jac(1), jac(3), neg(a[2]), neg(jac(7)), jac(4), inf2, inf2, O.jac_from_affine(F, pool[6])]
     bad = (a[0][0], F.add(a[0][1], F.one), a[0][2])                       # off the curve
     return {
+        IN_SUBGROUP: ([a[0], bad, inf, jac(13), outside_subgroup(group, 1), O.jac_rerandomise(F, outside_subgroup(group, 2), _rand_el(group, rng))], None),
         ADD: (a, b),
         DOUBLE: ([jac(2), jac(11), inf, O.jac_from_affine(F, pool[1])], None),
         NORMALIZE: ([jac(4), inf, O.jac_from_affine(F, pool[8]), jac(15)], None),
         EQ: ([a[1], a[0], inf, inf, a[3], a[2]], [b[1], b[0], inf2, jac(1), neg(b[3]), b[2]]),
         ON_CURVE: ([a[0], bad, inf, jac(12), O.jac_from_affine(F, pool[0])], None),
     }
+
+
+def outside_subgroup(group, which):
+    """A point ON the curve that is NOT in the order-r subgroup (the cofactors are far from 1, so the first abscissa tried
+    works): smallest x = which, which + 1, ... with x^3 + b a square; checked with the oracle's scalar multiplication."""
+    F = _field(group)
+    x = which
+    while True:
+        xx = x if group == 1 else (x, 1)
+        pt, fl = O.decompress_point(group, xx, 0)
+        if pt is not None:
+            j = O.jac_from_affine(F, pt)
+            assert O.jac_on_curve(F, j)
+            if not F.is_zero(O.jac_scalar_mul(F, j, O.R_ORDER)[2]):
+                return j
+        x += 1
 
 
 def expected(group, op, a, b):
@@ -60,6 +77,8 @@ def expected(group, op, a, b):
         r = [O.jac_normalize(F, x) for x in a]
     elif op == EQ:
         return None, [(FLAG_INFINITY if F.is_zero(x[2]) else 0) | (FLAG_TRUE if O.jac_eq(F, x, y) else 0) for x, y in zip(a, b)]
+    elif op == IN_SUBGROUP:
+        return None, [(FLAG_INFINITY if F.is_zero(x[2]) else 0) | (FLAG_TRUE if O.jac_in_subgroup(F, x) else 0) for x in a]
     else:
         return None, [(FLAG_INFINITY if F.is_zero(x[2]) else 0) | (FLAG_TRUE if O.jac_on_curve(F, x) else 0) for x in a]
     return r, [FLAG_INFINITY if F.is_zero(p[2]) else 0 for p in r]

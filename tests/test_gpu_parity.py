@@ -156,6 +156,36 @@ def test_point_surface_g1_g2(engine):
     assert engine.lib.bls381_g2_op_batch(engine._ctx, 9, pa, None, pa, None, 4) == 1
 
 
+def test_point_decompression(engine):
+    """bls381_g1/g2_decompress_batch vs the oracle: both signs of pool points, the infinity marker, abscissas off the curve
+    (flagged, zero output) and an on-curve abscissa outside the subgroup (decompression succeeds; the subgroup predicate says no)."""
+    from blsutil import point_pool
+    import point_cases
+    p1, p2 = point_pool(12)
+    for group, pool in ((1, p1), (2, p2)):
+        w = 1 if group == 1 else 2
+        flat = (lambda v: [v]) if group == 1 else (lambda v: list(v))
+        xs, sg = [], []
+        for pt in pool:
+            s0 = int(O.sgn0_fq(pt[1]) if group == 1 else O.sgn0_fq2(pt[1]))
+            xs += [pt[0], pt[0]]; sg += [s0, 1 - s0]
+        xs.append(pool[0][0]); sg.append(2 | 1)                                         # infinity marker wins
+        off = next(x for x in range(1, 200) if O.decompress_point(group, x if group == 1 else (x, 3), 0)[0] is None)
+        xs.append(off if group == 1 else (off, 3)); sg.append(0)
+        outside = O.jac_to_affine(O._F1 if group == 1 else O._F2, point_cases.outside_subgroup(group, 1))
+        xs.append(outside[0]); sg.append(int(O.sgn0_fq(outside[1]) if group == 1 else O.sgn0_fq2(outside[1])))
+        out, fl = engine.decompress(group, enc_fps([c for x in xs for c in flat(x)]), np.array(sg, dtype=np.uint8))
+        got = dec_fps(out)
+        for i, (x, s) in enumerate(zip(xs, sg)):
+            pt, efl = O.decompress_point(group, x, s)
+            exp = [0] * (2 * w) if pt is None else flat(pt[0]) + flat(pt[1])
+            assert got[2 * w * i:2 * w * (i + 1)] == exp and fl[i] == efl, (group, i)
+        assert got[-2 * w:] == flat(outside[0]) + flat(outside[1])
+        jac = np.concatenate([out.reshape(len(xs), 12 * w)[[0, -1]], np.tile(enc_fps(flat(1 if group == 1 else (1, 0))), (2, 1))], axis=1).reshape(-1)
+        _, sub = engine.point_op(group, B.POINT_IS_IN_SUBGROUP, jac)
+        assert list(sub & B.FLAG_TRUE) == [B.FLAG_TRUE, 0]
+
+
 def test_tower_identities_kat5(engine):
     """x^2 == x*x and (a+b) c^2 == c^2 a + c^2 b on device (the reference's test_fq12_arithmetic shape)."""
     rng = random.Random(55)
@@ -408,6 +438,62 @@ def test_mode_a_64k_batch_properties(engine, coracle):
     o = out.reshape(n // pool, pool * 72)
     exp, _ = coracle.miller_ref_opt(g1[: pool * 18], g2[: pool * 36], threads=16)
     assert np.array_equal(o[0], exp) and (o == o[0]).all() and not fl.any()
+
+
+def test_host_pointer_pipeline_pieces_and_slot_reuse(engine, coracle, pools):
+    """The host-pointer entry points move batches above 1.5 * 2^19 elements in pieces of 2^19 through two device slots
+    (upload of piece i+1 and download of piece i-1 under the kernels of piece i): n = 2^20 + 77 is three pieces, so both slots
+    are reused.  Every element against the resident `_dev` path, a sample against the oracle; a reused output buffer."""
+    import torch
+    from bls381_amd import synthetic
+    n = (1 << 20) + 77
+    g1, g2 = synthetic.affine_batch(pools, n, 1, first=31337)
+    out = np.empty(n * 72, dtype=np.uint64)
+    o2, fl = engine.multi_pairing(g1, g2, 1, out=out)
+    assert o2 is out and not fl.any()
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev); d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    dout = torch.zeros(n * 72, dtype=torch.int64, device=dev)
+    engine.multi_pairing_dev(d1.data_ptr(), d2.data_ptr(), 1, dout.data_ptr(), 0, n)
+    engine.sync()
+    assert np.array_equal(dout.cpu().numpy().view(np.uint64), out)
+    assert _oracle_sample(coracle, g1, g2, out, n, 512)
+    out[:] = 0
+    engine.multi_pairing(g1[: 12 * 1000], g2[: 24 * 1000], 1)              # a small call in between re-uses slot 0
+    engine.multi_pairing(g1, g2, 1, out=out)
+    assert np.array_equal(dout.cpu().numpy().view(np.uint64), out)
+
+
+def test_multi_device_context_shards_contiguous_ranges(coracle):
+    """bls381_create_multi / *_sharded: one host process, one context per listed device, contiguous ranges on host threads.
+    The box has one GPU, so it is listed twice and three times (two / three contexts, ranges of different sizes) and once by
+    default (every visible device); n = 1 leaves contexts with empty ranges."""
+    for ids, n, k in (([0, 0], 3001, 1), ([0, 0, 0], 500, 3), (None, 257, 1), ([0, 0], 1, 1)):
+        m = B.MultiEngine(ids)
+        try:
+            assert m.device_count == (len(ids) if ids else 1)
+            g1, g2 = synthetic_batch(n, seed=555 + n, jacobian=False, k=k, pool=40)
+            exp, efl = coracle.multi(g1, g2, k, final_exp=True, threads=16)
+            out, fl = m.multi_pairing(g1, g2, k)
+            assert np.array_equal(out, exp) and np.array_equal(fl, efl), (ids, n, k)
+            expm, _ = coracle.multi(g1, g2, k, final_exp=False, threads=16)
+            outm, _ = m.multi_miller_loop(g1, g2, k)
+            assert np.array_equal(outm, expm)
+        finally:
+            m.close()
+    m = B.MultiEngine([0, 0])
+    try:
+        j1, j2 = synthetic_batch(301, seed=77, jacobian=True, pool=30)
+        exp, efl = coracle.miller_ref_opt(j1, j2, threads=16)
+        out, fl = m.optimized_miller_loop(j1, j2)
+        assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+        m.set_option(B.OPT_FEXP_MODE, B.FEXP_SELF_CONTAINED)
+        with pytest.raises(B.Bls381Error):
+            m.set_option(B.OPT_BLOCK_SIZE, 100)
+    finally:
+        m.close()
+    with pytest.raises(B.Bls381Error):
+        B.MultiEngine([0, 99])
 
 
 def test_device_pointer_api_on_caller_stream(engine, coracle):

@@ -168,3 +168,23 @@ def test_kat5_reference_fixed_inputs_fq12():
         assert O.fp12_sqr(x) == O.fp12_mul(x, x)
     c2 = O.fp12_sqr(c)
     assert O.fp12_mul(add12(a, b), c2) == add12(O.fp12_mul(c2, a), O.fp12_mul(c2, b))
+
+
+def test_decompression_and_subgroup_oracle_round_trip():
+    """oracle/pyref.py decompress_point / jac_in_subgroup: (x, sgn0(y)) of a subgroup point gives the point back; the other sign
+    gives its negative; an x off the curve is refused; the generators are in the subgroup, a random curve point is not."""
+    from blsutil import point_pool
+    p1, p2 = point_pool(6)
+    for pt in p1:
+        assert O.decompress_point(1, pt[0], int(O.sgn0_fq(pt[1]))) == ((pt[0], pt[1]), 0)
+        assert O.decompress_point(1, pt[0], int(not O.sgn0_fq(pt[1])))[0] == (pt[0], (-pt[1]) % O.P)
+    for q in p2:
+        assert O.decompress_point(2, q[0], int(O.sgn0_fq2(q[1]))) == ((q[0], q[1]), 0)
+    assert O.decompress_point(1, 5, 2) == (None, O.FLAG_INFINITY)
+    bad = next(x for x in range(1, 50) if O.fp_sqrt_any((x ** 3 + 4) % O.P) is None)
+    assert O.decompress_point(1, bad, 0) == (None, O.WFLAG_NOT_SQUARE)
+    import point_cases
+    for group, F, gen in ((1, O._F1, O.G1_GEN), (2, O._F2, O.G2_GEN)):
+        assert O.jac_in_subgroup(F, O.jac_from_affine(F, gen))
+        out = point_cases.outside_subgroup(group, 1)
+        assert O.jac_on_curve(F, out) and not O.jac_in_subgroup(F, out)
