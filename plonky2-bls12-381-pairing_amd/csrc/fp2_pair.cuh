@@ -139,6 +139,24 @@ BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   }
 }
 
+// Lazy sums of Fp2 products (fp.cuh `dot`): A_1 B_1 + ... + A_N B_N with one reduction per lane.  Each lane runs the two
+// Fp products of mul_raw per Fp2 product -- even: a0 b0 + (-a1) b1 ; odd: a0 b1 + a1 b0 -- into the same accumulators.
+template <class A, class B> struct Fp2Prod { const A& a; const B& b; };
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>> pr2(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>>{a, b}; }
+template <class A0, class A1, class B0> struct Fp2LaneOps { A0 a0; A1 a1s; B0 b, bo; };
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto fp2_lane_ops(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+  const bool even = lane_part() == 0;
+  const Fp<La, Va> a1 = bcast1(a.v);
+  const auto a1s = sel(even, neg(a1), a1);
+  return Fp2LaneOps<Fp<La, Va>, decltype(sel(even, neg(a1), a1)), Fp<Lb, Vb>>{bcast0(a.v), a1s, b.v, swap(b.v)};
+}
+template <class... O>
+BLS_HD Fp2R dot2_ops(const O&... o) { return Fp2R(dot(pr(o.a0, o.b)..., pr(o.a1s, o.bo)...)); }
+template <class... P>
+BLS_HD Fp2R dot2(const P&... p) { return dot2_ops(fp2_lane_ops(p.a, p.b)...); }
+
 // even: (a0 + a1)(a0 - a1) ; odd: (a0 + a0) a1      -- fq2_target_tree.rs:80-91
 template <int L, int V>
 BLS_HD Fp2R sqr(const Fp2<L, V>& a) {

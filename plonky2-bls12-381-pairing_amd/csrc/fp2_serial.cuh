@@ -72,6 +72,22 @@ BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   }
 }
 
+// Lazy sums of Fp2 products (fp.cuh `dot`): A_1 B_1 + ... + A_N B_N with one reduction per coefficient.
+template <class A, class B> struct Fp2Prod { const A& a; const B& b; };
+template <int La, int Va, int Lb, int Vb>
+BLS_HD Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>> pr2(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>>{a, b}; }
+template <class A0, class A1, class A1N, class B0> struct Fp2SerialOps { A0 a0; A1 a1; A1N a1n; B0 b0, b1; };
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto fp2_serial_ops(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+  return Fp2SerialOps<Fp<La, Va>, Fp<La, Va>, decltype(neg(a.c1)), Fp<Lb, Vb>>{a.c0, a.c1, neg(a.c1), b.c0, b.c1};
+}
+template <class... O>
+BLS_HD Fp2R dot2_ops(const O&... o) {
+  return Fp2R(dot(pr(o.a0, o.b0)..., pr(o.a1n, o.b1)...), dot(pr(o.a0, o.b1)..., pr(o.a1, o.b0)...));
+}
+template <class... P>
+BLS_HD Fp2R dot2(const P&... p) { return dot2_ops(fp2_serial_ops(p.a, p.b)...); }
+
 // complex squaring (a0+a1)(a0-a1), 2 a0 a1   -- fq2_target_tree.rs:80-91
 template <int L, int V>
 BLS_HD Fp2R sqr(const Fp2<L, V>& a) {

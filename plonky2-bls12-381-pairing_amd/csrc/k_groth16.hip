@@ -6,6 +6,10 @@
 // of three; every lane reads the shared coefficients as LDS broadcasts.
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
+// one wave per SIMD: every instruction costs one issue slot, so the sparse line multiplication runs as lazy sums (tower.cuh)
+#ifndef BLS_LAZY_014
+#define BLS_LAZY_014 1
+#endif
 #include "pairing.cuh"
 #include "launch.h"
 using namespace bls;

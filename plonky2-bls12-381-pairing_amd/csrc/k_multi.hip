@@ -2,6 +2,10 @@
 // several TUs only to compile them in parallel; each exposes plain host launch functions (launch.h).
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
+// one wave per SIMD: every instruction costs one issue slot, so the sparse line multiplication runs as lazy sums (tower.cuh)
+#ifndef BLS_LAZY_014
+#define BLS_LAZY_014 1
+#endif
 #include "pairing.cuh"
 #include "launch.h"
 using namespace bls;
