@@ -238,29 +238,34 @@ BLS_HD void mont_acc_reduce(uint32_t (&out)[NL], uint64_t (&acc)[2 * NL - 1]) {
   out[NL - 1] = (uint32_t)carry;
 }
 
-// one product of a lazy sum: references to its two factors (bounds travel in the types)
+// A term of a lazy sum is anything with compile-time bounds `ll` (sum of La Lb) and `vv` (sum of Va Vb) of the products it adds
+// and accumulate<C>(acc), C = the coefficient being computed (used by the serial Fp2 backend; 0 here).
+// One Fp product: references to its two factors (bounds travel in the types).
 template <class A, class B> struct FpProd {
   const A& a; const B& b;
   static constexpr int ll = A::kL * B::kL, vv = A::kV * B::kV;
+  template <int C> BLS_HD void accumulate(uint64_t (&acc)[2 * NL - 1]) const { mont_acc_product(acc, a.l, b.l); }
 };
 template <int La, int Va, int Lb, int Vb>
 BLS_HD FpProd<Fp<La, Va>, Fp<Lb, Vb>> pr(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) { return FpProd<Fp<La, Va>, Fp<Lb, Vb>>{a, b}; }
 
-// dot(pr(a1, b1), ..., pr(aN, bN)) = (a1 b1 + ... + aN bN) / R  (mod p), result < 2p, limbs normalised
-template <class... P>
-BLS_HD FpR dot(const P&... p) {
-  static_assert((0 + ... + P::ll) <= MONT_LL_MAX, "dot: limb bounds overflow the 64-bit column accumulators");
-  static_assert((0 + ... + P::vv) <= MONT_VV_MAX, "dot: value bounds break the < 2p result guarantee");
+template <int C, class... T>
+BLS_HD FpR dot_terms(const T&... t) {
+  static_assert((0 + ... + T::ll) <= MONT_LL_MAX, "dot: limb bounds overflow the 64-bit column accumulators");
+  static_assert((0 + ... + T::vv) <= MONT_VV_MAX, "dot: value bounds break the < 2p result guarantee");
   BLS_COUNT(6);
   uint64_t acc[2 * NL - 1];
 #pragma unroll
   for (int k = 0; k < 2 * NL - 1; ++k) acc[k] = 0;
-  (mont_acc_product(acc, p.a.l, p.b.l), ...);
+  (t.template accumulate<C>(acc), ...);
   FpR r;
   mont_acc_reduce(r.l, acc);
   r.chk();
   return r;
 }
+// dot(pr(a1, b1), ..., pr(aN, bN)) = (a1 b1 + ... + aN bN) / R  (mod p), result < 2p, limbs normalised
+template <class... P>
+BLS_HD FpR dot(const P&... p) { return dot_terms<0>(p...); }
 
 // ------------------------------------------------------------------------------------------------
 // additions: limb-wise, no carries.  When the result would leave the representable bounds (limb < 15 * 2^28,

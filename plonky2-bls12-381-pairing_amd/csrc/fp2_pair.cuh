@@ -139,23 +139,47 @@ BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   }
 }
 
-// Lazy sums of Fp2 products (fp.cuh `dot`): A_1 B_1 + ... + A_N B_N with one reduction per lane.  Each lane runs the two
-// Fp products of mul_raw per Fp2 product -- even: a0 b0 + (-a1) b1 ; odd: a0 b1 + a1 b0 -- into the same accumulators.
+// Lazy sums of Fp2 products and squares (fp.cuh `dot_terms`): one reduction per lane for
+//     dot2(pr2(A1, B1), sq2(A2), ...) = A1 B1 + A2^2 + ...
+// A product contributes the two Fp products of mul_raw on each lane -- even: a0 b0 + (-a1) b1 ; odd: a0 b1 + a1 b0 --, a square
+// the one of sqr -- even: (a0 + a1)(a0 - a1) ; odd: (2 a0) a1.
 template <class A, class B> struct Fp2Prod { const A& a; const B& b; };
 template <int La, int Va, int Lb, int Vb>
 BLS_HD Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>> pr2(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>>{a, b}; }
-template <class A0, class A1, class B0> struct Fp2LaneOps { A0 a0; A1 a1s; B0 b, bo; };
+template <class A> struct Fp2Sq { const A& a; };
+template <int L, int V>
+BLS_HD Fp2Sq<Fp2<L, V>> sq2(const Fp2<L, V>& a) { return Fp2Sq<Fp2<L, V>>{a}; }
+
+template <class A0, class A1, class B0> struct Fp2MulTerm {
+  A0 a0; A1 a1s; B0 b, bo;
+  static constexpr int ll = A0::kL * B0::kL + A1::kL * B0::kL, vv = A0::kV * B0::kV + A1::kV * B0::kV;
+  template <int C> BLS_HD void accumulate(uint64_t (&acc)[2 * NL - 1]) const {
+    mont_acc_product(acc, a0.l, b.l);
+    mont_acc_product(acc, a1s.l, bo.l);
+  }
+};
+template <class X, class Y> struct Fp2SqTerm {
+  X x; Y y;
+  static constexpr int ll = X::kL * Y::kL, vv = X::kV * Y::kV;
+  template <int C> BLS_HD void accumulate(uint64_t (&acc)[2 * NL - 1]) const { mont_acc_product(acc, x.l, y.l); }
+};
 template <int La, int Va, int Lb, int Vb>
-BLS_HD auto fp2_lane_ops(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+BLS_HD auto fp2_term(const Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>>& p) {
   const bool even = lane_part() == 0;
-  const Fp<La, Va> a1 = bcast1(a.v);
+  const Fp<La, Va> a1 = bcast1(p.a.v);
   const auto a1s = sel(even, neg(a1), a1);
-  return Fp2LaneOps<Fp<La, Va>, decltype(sel(even, neg(a1), a1)), Fp<Lb, Vb>>{bcast0(a.v), a1s, b.v, swap(b.v)};
+  return Fp2MulTerm<Fp<La, Va>, decltype(sel(even, neg(a1), a1)), Fp<Lb, Vb>>{bcast0(p.a.v), a1s, p.b.v, swap(p.b.v)};
 }
-template <class... O>
-BLS_HD Fp2R dot2_ops(const O&... o) { return Fp2R(dot(pr(o.a0, o.b)..., pr(o.a1s, o.bo)...)); }
-template <class... P>
-BLS_HD Fp2R dot2(const P&... p) { return dot2_ops(fp2_lane_ops(p.a, p.b)...); }
+template <int L, int V>
+BLS_HD auto fp2_term(const Fp2Sq<Fp2<L, V>>& s) {
+  const bool even = lane_part() == 0;
+  const Fp<L, V> o = swap(s.a.v);
+  const auto x = add(bcast0(s.a.v), o);
+  const auto y = sel(even, sub(s.a.v, o), s.a.v);
+  return Fp2SqTerm<decltype(add(bcast0(s.a.v), o)), decltype(sel(even, sub(s.a.v, o), s.a.v))>{x, y};
+}
+template <class... T>
+BLS_HD Fp2R dot2(const T&... t) { return Fp2R(dot_terms<0>(fp2_term(t)...)); }
 
 // even: (a0 + a1)(a0 - a1) ; odd: (a0 + a0) a1      -- fq2_target_tree.rs:80-91
 template <int L, int V>

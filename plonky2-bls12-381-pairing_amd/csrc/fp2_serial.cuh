@@ -72,21 +72,42 @@ BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   }
 }
 
-// Lazy sums of Fp2 products (fp.cuh `dot`): A_1 B_1 + ... + A_N B_N with one reduction per coefficient.
+// Lazy sums of Fp2 products and squares (fp.cuh `dot_terms`): one reduction per coefficient for
+//     dot2(pr2(A1, B1), sq2(A2), ...) = A1 B1 + A2^2 + ...
 template <class A, class B> struct Fp2Prod { const A& a; const B& b; };
 template <int La, int Va, int Lb, int Vb>
 BLS_HD Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>> pr2(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) { return Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>>{a, b}; }
-template <class A0, class A1, class A1N, class B0> struct Fp2SerialOps { A0 a0; A1 a1; A1N a1n; B0 b0, b1; };
+template <class A> struct Fp2Sq { const A& a; };
+template <int L, int V>
+BLS_HD Fp2Sq<Fp2<L, V>> sq2(const Fp2<L, V>& a) { return Fp2Sq<Fp2<L, V>>{a}; }
+
+template <class A0, class A1N, class B0> struct Fp2MulTerm {      // C = 0: a0 b0 + (-a1) b1 ; C = 1: a0 b1 + a1 b0
+  A0 a0, a1; A1N a1n; B0 b0, b1;
+  static constexpr int ll = A0::kL * B0::kL + A1N::kL * B0::kL, vv = A0::kV * B0::kV + A1N::kV * B0::kV;
+  template <int C> BLS_HD void accumulate(uint64_t (&acc)[2 * NL - 1]) const {
+    if (C == 0) { mont_acc_product(acc, a0.l, b0.l); mont_acc_product(acc, a1n.l, b1.l); }
+    else { mont_acc_product(acc, a0.l, b1.l); mont_acc_product(acc, a1.l, b0.l); }
+  }
+};
+template <class S, class D, class A> struct Fp2SqTerm {           // C = 0: (a0 + a1)(a0 - a1) ; C = 1: (2 a0) a1
+  S s, t; D d; A a1;
+  static constexpr int ll = S::kL * D::kL, vv = S::kV * D::kV;
+  template <int C> BLS_HD void accumulate(uint64_t (&acc)[2 * NL - 1]) const {
+    if (C == 0) mont_acc_product(acc, s.l, d.l); else mont_acc_product(acc, t.l, a1.l);
+  }
+};
 template <int La, int Va, int Lb, int Vb>
-BLS_HD auto fp2_serial_ops(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
-  return Fp2SerialOps<Fp<La, Va>, Fp<La, Va>, decltype(neg(a.c1)), Fp<Lb, Vb>>{a.c0, a.c1, neg(a.c1), b.c0, b.c1};
+BLS_HD auto fp2_term(const Fp2Prod<Fp2<La, Va>, Fp2<Lb, Vb>>& p) {
+  return Fp2MulTerm<Fp<La, Va>, decltype(neg(p.a.c1)), Fp<Lb, Vb>>{p.a.c0, p.a.c1, neg(p.a.c1), p.b.c0, p.b.c1};
 }
-template <class... O>
-BLS_HD Fp2R dot2_ops(const O&... o) {
-  return Fp2R(dot(pr(o.a0, o.b0)..., pr(o.a1n, o.b1)...), dot(pr(o.a0, o.b1)..., pr(o.a1, o.b0)...));
+template <int L, int V>
+BLS_HD auto fp2_term(const Fp2Sq<Fp2<L, V>>& q) {
+  return Fp2SqTerm<Fp<2 * L, 2 * V>, decltype(sub(q.a.c0, q.a.c1)), Fp<L, V>>{add(q.a.c0, q.a.c1), dbl(q.a.c0), sub(q.a.c0, q.a.c1), q.a.c1};
 }
-template <class... P>
-BLS_HD Fp2R dot2(const P&... p) { return dot2_ops(fp2_serial_ops(p.a, p.b)...); }
+template <class... T>
+BLS_HD Fp2R dot2_terms(const T&... t) { return Fp2R(dot_terms<0>(t...), dot_terms<1>(t...)); }
+template <class... T>
+BLS_HD Fp2R dot2(const T&... t) { return dot2_terms(fp2_term(t)...); }
 
 // complex squaring (a0+a1)(a0-a1), 2 a0 a1   -- fq2_target_tree.rs:80-91
 template <int L, int V>

@@ -334,14 +334,13 @@ BLS_HD LineCoeffs doubling_step_hom(G2Jac& r) {
   const auto H = fit<1, 2>(sub(sub(sqr(add(r.y, r.z)), B), C));   // 2 Y Z
   const auto I = fit<1, 2>(sub(E, B));
   const Fp2R J = sqr(r.x);
-  const Fp2R E2 = sqr(E);
-  const auto e12 = dbl(dbl(add(dbl(E2), E2)));                    // 12 E^2
   LineCoeffs l;
   l.c = I;
   l.b = fit<1, 2>(add(dbl(J), J));
   l.a = fit<1, 2>(neg(H));
   const auto X3 = fit<1, 2>(dbl(mul(A, sub(B, F))));
-  const auto Y3 = fit<1, 2>(sub(sqr(G), e12));
+  const auto m12e = fit<1, 64>(neg(dbl(dbl(add(dbl(E), E)))));   // -12 E
+  const Fp2R Y3 = dot2(sq2(fit<1, 64>(G)), pr2(m12e, E));        // G^2 - 12 E^2 with one reduction
   const auto Z3 = fit<1, 2>(dbl(dbl(mul(B, H))));
   r.x = X3; r.y = Y3; r.z = Z3;
   return l;
@@ -356,14 +355,14 @@ BLS_HD LineCoeffs addition_step_hom(G2Jac& r_io, const G2Aff& q) {
   const Fp2R f = mul(r.z, c);
   const Fp2R g = mul(r.x, d);
   const auto h = fit<1, 2>(sub(add(e, f), dbl(g)));
-  const auto j = fit<1, 2>(sub(mul(theta, q.x), mul(lambda, q.y)));
+  const Fp2R j = dot2(pr2(theta, q.x), pr2(fit<1, 64>(neg(lambda)), q.y));          // theta xq - lambda yq, one reduction
   LineCoeffs l;
   l.c = j;
   l.b = fit<1, 2>(neg(theta));
   l.a = lambda;
   G2Jac o;
   o.x = mul(lambda, h);
-  o.y = fit<1, 2>(sub(mul(theta, sub(g, h)), mul(e, r.y)));
+  o.y = dot2(pr2(theta, fit<1, 64>(sub(g, h))), pr2(fit<1, 64>(neg(e)), r.y));     // theta (g - h) - e Y, one reduction
   o.z = mul(r.z, e);
   r_io = o;
   return l;

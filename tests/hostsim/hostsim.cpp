@@ -5,6 +5,7 @@
 // without a GPU and (2) verify at run time every static limb/value bound the lazy-reduction types claim.
 // The product library has no CPU path: it fails loudly without a GPU.
 #define BLS_BOUND_CHECK 1
+#define BLS_LAZY_014 1      // the form the Miller kernels compile (k_multi.hip, k_groth16.hip); Karatsuba stays reachable as op 11
 #include "pairing.cuh"
 #include "witness.cuh"
 #include "fexp_stages.cuh"
@@ -178,6 +179,10 @@ int hostsim_fp12_op(int op, int form, const uint64_t* a, const uint64_t* b, uint
       case OP12_CONJ: r = fit<1, 2>(conj(x)); break;
       case OP12_CYC_EXP: r = cyclotomic_exp(x); break;
       case OP12_FINAL_EXP: r = final_exponentiation(x); break;
+      // sparse line multiplication, factor (c0, c1, c4) = (y.c0.c0, y.c0.c1, y.c1.c1): 10 = the form the library's Miller
+      // kernels compile (lazy sums, BLS_LAZY_014), 11 = Karatsuba as the reference writes it (fq12_target_tree.rs:157-176)
+      case 10: r = mul_by_014_lazy(x, y.c0.c0, y.c0.c1, y.c1.c1); break;
+      case 11: r = mul_by_014(x, y.c0.c0, y.c0.c1, y.c1.c1); break;
       default: return 1;
     }
     fp12_store(out + 72 * i, r, form);

@@ -62,6 +62,21 @@ def test_tower_golden(hostsim):
     assert dec_fp12s(hostsim.fp12_op(6, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
 
 
+def test_mul_by_014_lazy_sums_and_karatsuba(hostsim):
+    """The sparse line multiplication in the two forms of csrc/tower.cuh -- six three-product sums with one reduction each
+    (what the Miller kernels compile) and Karatsuba over Fp6 -- against the oracle's mul_by_014
+    (fields_as_trees/fq12_target_tree.rs:157-176), bound checks on."""
+    rng = random.Random(14)
+    fs = [rand_fp12(rng) for _ in range(9)]
+    ys = [rand_fp12(rng) for _ in range(9)]
+    ys[3] = O.fp12_unflatten([0] * 12)
+    fs[5] = O.fp12_unflatten([O.P - 1] * 12)
+    X = enc_fp12s(fs); Y = enc_fp12s(ys)
+    exp = [O.fp12_mul_by_014(f, y[0][0], y[0][1], y[1][1]) for f, y in zip(fs, ys)]
+    assert dec_fp12s(hostsim.fp12_op(10, X, Y)) == exp
+    assert dec_fp12s(hostsim.fp12_op(11, X, Y)) == exp
+
+
 def test_final_exp_split_with_batched_inversion(hostsim):
     """The three-kernel form of the final exponentiation (norms -> simultaneous inversion in chunks of eight -> finish)
     gives the oracle's bits for every element, whatever the chunk alignment; zero elements stay zero and do not disturb
