@@ -13,14 +13,19 @@
 // f^|x| = f^(2^63) f^(2^62) f^(2^60) f^(2^57) f^(2^48) f^(2^16): the compressed chain is walked once, the six marked
 // powers are parked in scratch, their six denominators share one inversion, then five multiplications.
 //
-// Six stage kernels (k_fexp.hip) with a batch inversion between consecutive ones:
-//   1  f^-1 from the supplied norm inverse, easy part -> t2; t1 = conj(t2^2);               start exp(t2)
-//   2  t3 = exp(t2); t4 = t3^2; t5 = t1 t3; u = conj(t5) t2;                                 start exp(t5)
-//   3  t1' = exp(t5); v = frob^3(t1' t2);                                                    start exp(t1')
-//   4  t0 = exp(t1'); w = frob^2(t3 t0) v;                                                   start exp(t0)
-//   5  t6 = exp(t0) t4; w = w frob(t6 conj(t2));                                             start exp(t6)
-//   6  result = w (exp(t6) u)
-// which is f_conversion (:128-164) regrouped so that each value is parked at most once.
+// Six stage kernels (k_fexp.hip) with a batch inversion between consecutive ones.  The hard part is walked along
+//     3 (p^4 - p^2 + 1) / r  =  (x - 1)^2 (x + p) (x^2 + p^2 - 1) + 3          (Hayashida-Hayasaka-Teruya; integer identity,
+// checked in tests/test_oracle_kats.py), the SAME exponent f_conversion (:137-163) reaches with its own addition chain -- hence
+// the same field element, bit for bit -- but with 9 Fq12 products, 3 Frobenius maps and 1 cyclotomic squaring around the five
+// exponentiations by x instead of 12, 8 and 2, and three parked Fq12 values instead of six.  With m the easy-part value and
+// E(g) = g^x = conj(g^|x|):
+//   1  f^-1 from the supplied norm inverse, easy part -> m (:166-178, :133-136);        start E(m)
+//   2  a = E(m) conj(m)               = m^(x-1);                                        start E(a)
+//   3  b = E(a) conj(a)               = a^(x-1);                                        start E(b)
+//   4  c = E(b) frob(b)               = b^(x+p);                                        start E(c)
+//   5  d1 = E(c);  W = frob^2(c) conj(c) (m^2 m);                                       start E(d1)
+//   6  result = E(d1) W               = c^(x^2+p^2-1) m^3
+// The one-kernel forms (tower.cuh final_exponentiation*) keep the reference's own chain; tests compare all of them.
 #pragma once
 #include "tower.cuh"
 
@@ -89,12 +94,12 @@ BLS_HD Fp12R decompress(const Fp12C& g, const Fp2R& den_inv) {
 }
 
 // ------------------------------------------------------------------------------------------ scratch layout
-// Per element, in units of Fp2 values inside a LaneScratch (fp.cuh): six Fq12 slots, the six compressed powers of the
+// Per element, in units of Fp2 values inside a LaneScratch (fp.cuh): three Fq12 slots, the six compressed powers of the
 // running exponentiation, and the prefix products of their denominators.
-enum : int { FX_T2 = 0, FX_A = 1, FX_T3 = 2, FX_T4 = 3, FX_U = 4, FX_W = 5, FX_SLOTS = 6 };
+enum : int { FX_M = 0, FX_A = 1, FX_W = 2, FX_SLOTS = 3 };     // m; a, then b, then c; W
 constexpr int FX_COMP_BASE = FX_SLOTS * 6;
 constexpr int FX_PRE_BASE = FX_COMP_BASE + 6 * 4;
-constexpr int FX_FP2_TOTAL = FX_PRE_BASE + 6;                                    // 66 Fp2 per element
+constexpr int FX_FP2_TOTAL = FX_PRE_BASE + 6;                                    // 48 Fp2 per element
 constexpr int FX_DWORDS_PER_LANE = FX_FP2_TOTAL * SCRATCH_FP_PER_FP2 * 16;       // 16 dwords per parked Fp
 
 struct FexpScratch {
@@ -180,46 +185,37 @@ BLS_HD Fp12R frobenius_n(const Fp12R& a, int n) {
 BLS_HD void fexp_stage1(const Fp12R& f, const FexpScratch& sc) {
   const FpR f_norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
   const Fp12R f_inv = fp12_inv_given_call(f, f_norm_inv);
-  Fp12R t2 = mul_call(fit<1, 2>(conj(f)), f_inv);                       // :168-175, :133
-  t2 = mul_call(frobenius_n(t2, 2), t2);                                // :135-136
-  const Fp12R t1 = fit<1, 2>(conj(cyclotomic_square_call(t2)));         // :137
-  fx_put12(sc.ls, FX_T2, t2);
-  fx_put12(sc.ls, FX_A, t1);
-  fexp_start_exp(t2, sc);
+  Fp12R m = mul_call(fit<1, 2>(conj(f)), f_inv);                        // :168-175, :133
+  m = mul_call(frobenius_n(m, 2), m);                                   // :135-136
+  fx_put12(sc.ls, FX_M, m);
+  fexp_start_exp(m, sc);
 }
 BLS_HD void fexp_stage2(const FexpScratch& sc) {
-  const Fp12R t3 = fexp_finish_exp(sc);
-  const Fp12R t4 = cyclotomic_square_call(t3);
-  const Fp12R t5 = mul_call(fx_get12(sc.ls, FX_A), t3);
-  const Fp12R u = mul_call(fit<1, 2>(conj(t5)), fx_get12(sc.ls, FX_T2));
-  fx_put12(sc.ls, FX_T3, t3);
-  fx_put12(sc.ls, FX_T4, t4);
-  fx_put12(sc.ls, FX_U, u);
-  fexp_start_exp(t5, sc);
+  const Fp12R a = mul_call(fexp_finish_exp(sc), fit<1, 2>(conj(fx_get12(sc.ls, FX_M))));
+  fx_put12(sc.ls, FX_A, a);
+  fexp_start_exp(a, sc);
 }
 BLS_HD void fexp_stage3(const FexpScratch& sc) {
-  const Fp12R t1 = fexp_finish_exp(sc);
-  const Fp12R v = frobenius_n(mul_call(t1, fx_get12(sc.ls, FX_T2)), 3);
-  fx_put12(sc.ls, FX_A, v);
-  fexp_start_exp(t1, sc);
+  const Fp12R b = mul_call(fexp_finish_exp(sc), fit<1, 2>(conj(fx_get12(sc.ls, FX_A))));
+  fx_put12(sc.ls, FX_A, b);
+  fexp_start_exp(b, sc);
 }
 BLS_HD void fexp_stage4(const FexpScratch& sc) {
-  const Fp12R t0 = fexp_finish_exp(sc);
-  Fp12R w = frobenius_n(mul_call(fx_get12(sc.ls, FX_T3), t0), 2);
-  w = mul_call(w, fx_get12(sc.ls, FX_A));
-  fx_put12(sc.ls, FX_W, w);
-  fexp_start_exp(t0, sc);
+  const Fp12R c = mul_call(fexp_finish_exp(sc), frobenius_n(fx_get12(sc.ls, FX_A), 1));
+  fx_put12(sc.ls, FX_A, c);
+  fexp_start_exp(c, sc);
 }
 BLS_HD void fexp_stage5(const FexpScratch& sc) {
-  Fp12R t6 = fexp_finish_exp(sc);
-  t6 = mul_call(t6, fx_get12(sc.ls, FX_T4));
-  const Fp12R y = frobenius_n(mul_call(t6, fit<1, 2>(conj(fx_get12(sc.ls, FX_T2)))), 1);
-  fx_put12(sc.ls, FX_W, mul_call(fx_get12(sc.ls, FX_W), y));
-  fexp_start_exp(t6, sc);
+  const Fp12R d1 = fexp_finish_exp(sc);
+  const Fp12R m = fx_get12(sc.ls, FX_M);
+  const Fp12R m3 = mul_call(cyclotomic_square_call(m), m);
+  const Fp12R c = fx_get12(sc.ls, FX_A);
+  const Fp12R w = mul_call(frobenius_n(c, 2), fit<1, 2>(conj(c)));
+  fx_put12(sc.ls, FX_W, mul_call(w, m3));
+  fexp_start_exp(d1, sc);
 }
 BLS_HD Fp12R fexp_stage6(const FexpScratch& sc) {
-  const Fp12R t4 = fexp_finish_exp(sc);
-  return mul_call(fx_get12(sc.ls, FX_W), mul_call(t4, fx_get12(sc.ls, FX_U)));
+  return mul_call(fexp_finish_exp(sc), fx_get12(sc.ls, FX_W));
 }
 
 }  // namespace bls
