@@ -99,7 +99,8 @@ BLS_HD Fp12R decompress(const Fp12C& g, const Fp2R& den_inv) {
 enum : int { FX_M = 0, FX_A = 1, FX_W = 2, FX_SLOTS = 3 };     // m; a, then b, then c; W
 constexpr int FX_COMP_BASE = FX_SLOTS * 6;
 constexpr int FX_PRE_BASE = FX_COMP_BASE + 6 * 4;
-constexpr int FX_FP2_TOTAL = FX_PRE_BASE + 6;                                    // 48 Fp2 per element
+constexpr int FX_X_BASE = FX_PRE_BASE + 6;                                       // input of the next squaring chain (split launch)
+constexpr int FX_FP2_TOTAL = FX_X_BASE + 4;                                      // 52 Fp2 per element
 constexpr int FX_DWORDS_PER_LANE = FX_FP2_TOTAL * SCRATCH_FP_PER_FP2 * 16;       // 16 dwords per parked Fp
 
 struct FexpScratch {
@@ -120,6 +121,13 @@ BLS_HD void fx_putc(const LaneScratch& s, int m, const Fp12C& g) {
   fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 0, g.z2); fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 1, g.z3);
   fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 2, g.z4); fp2_scratch_put(s, FX_COMP_BASE + 4 * m + 3, g.z5);
 }
+BLS_HD void fx_putx(const LaneScratch& s, const Fp12C& g) {
+  fp2_scratch_put(s, FX_X_BASE + 0, g.z2); fp2_scratch_put(s, FX_X_BASE + 1, g.z3);
+  fp2_scratch_put(s, FX_X_BASE + 2, g.z4); fp2_scratch_put(s, FX_X_BASE + 3, g.z5);
+}
+BLS_HD Fp12C fx_getx(const LaneScratch& s) {
+  return Fp12C{fp2_scratch_get(s, FX_X_BASE + 0), fp2_scratch_get(s, FX_X_BASE + 1), fp2_scratch_get(s, FX_X_BASE + 2), fp2_scratch_get(s, FX_X_BASE + 3)};
+}
 BLS_HD Fp12C fx_getc(const LaneScratch& s, int m) {
   return Fp12C{fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 0), fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 1),
                fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 2), fp2_scratch_get(s, FX_COMP_BASE + 4 * m + 3)};
@@ -132,8 +140,8 @@ static_assert(FX_MARKS == ((1ull << 63) | (1ull << 62) | (1ull << 60) | (1ull <<
 
 // first half: walk the compressed squaring chain, park the six marked powers and the prefix products of their
 // denominators, leave the Fp norm of the full denominator product for the batch inversion
-BLS_HD_NOINLINE void fexp_start_exp(const Fp12R& x, const FexpScratch& sc) {
-  Fp12C g = compress(x);
+BLS_HD void fexp_chain(const Fp12C& x, const FexpScratch& sc) {
+  Fp12C g = x;
   Fp2R prod = Fp2R(fp2_one());
   int m = 0;
   for (int k = 1; k <= 63; ++k) {
@@ -150,6 +158,7 @@ BLS_HD_NOINLINE void fexp_start_exp(const Fp12R& x, const FexpScratch& sc) {
   const FpR nrm = fp2_norm(prod);
   if (lane_part() == 0) raw_fp_store(sc.norm_raw + sc.elem * RAW_FP_STRIDE, nrm);
 }
+BLS_HD_NOINLINE void fexp_start_exp(const Fp12R& x, const FexpScratch& sc) { fexp_chain(compress(x), sc); }
 
 // second half: conj(x^|x|) from the parked powers and the inverse of the norm (== cyclotomic_exp(x), tower.cuh)
 BLS_FN_COLD Fp12R fexp_finish_exp(const FexpScratch& sc) {
@@ -182,38 +191,46 @@ BLS_HD Fp12R frobenius_n(const Fp12R& a, int n) {
   return r;
 }
 
-BLS_HD void fexp_stage1(const Fp12R& f, const FexpScratch& sc) {
+// Each stage = its glue (Fq12 products around the exponentiation just finished; returns the value whose exponentiation starts
+// next) followed by that value's squaring chain.  The two halves can run fused in one kernel (k_fexp_stage<i>, two waves per
+// SIMD) or as two launches with the glue compiled for one wave per SIMD (k_fexp_glue + k_fexp_chain, k_fexp_wide.hip / k_fexp.hip).
+BLS_HD Fp12R fexp_glue1(const Fp12R& f, const FexpScratch& sc) {
   const FpR f_norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
   const Fp12R f_inv = fp12_inv_given_call(f, f_norm_inv);
   Fp12R m = mul_call(fit<1, 2>(conj(f)), f_inv);                        // :168-175, :133
   m = mul_call(frobenius_n(m, 2), m);                                   // :135-136
   fx_put12(sc.ls, FX_M, m);
-  fexp_start_exp(m, sc);
+  return m;
 }
-BLS_HD void fexp_stage2(const FexpScratch& sc) {
+BLS_HD Fp12R fexp_glue2(const FexpScratch& sc) {
   const Fp12R a = mul_call(fexp_finish_exp(sc), fit<1, 2>(conj(fx_get12(sc.ls, FX_M))));
   fx_put12(sc.ls, FX_A, a);
-  fexp_start_exp(a, sc);
+  return a;
 }
-BLS_HD void fexp_stage3(const FexpScratch& sc) {
+BLS_HD Fp12R fexp_glue3(const FexpScratch& sc) {
   const Fp12R b = mul_call(fexp_finish_exp(sc), fit<1, 2>(conj(fx_get12(sc.ls, FX_A))));
   fx_put12(sc.ls, FX_A, b);
-  fexp_start_exp(b, sc);
+  return b;
 }
-BLS_HD void fexp_stage4(const FexpScratch& sc) {
+BLS_HD Fp12R fexp_glue4(const FexpScratch& sc) {
   const Fp12R c = mul_call(fexp_finish_exp(sc), frobenius_n(fx_get12(sc.ls, FX_A), 1));
   fx_put12(sc.ls, FX_A, c);
-  fexp_start_exp(c, sc);
+  return c;
 }
-BLS_HD void fexp_stage5(const FexpScratch& sc) {
+BLS_HD Fp12R fexp_glue5(const FexpScratch& sc) {
   const Fp12R d1 = fexp_finish_exp(sc);
   const Fp12R m = fx_get12(sc.ls, FX_M);
   const Fp12R m3 = mul_call(cyclotomic_square_call(m), m);
   const Fp12R c = fx_get12(sc.ls, FX_A);
   const Fp12R w = mul_call(frobenius_n(c, 2), fit<1, 2>(conj(c)));
   fx_put12(sc.ls, FX_W, mul_call(w, m3));
-  fexp_start_exp(d1, sc);
+  return d1;
 }
+BLS_HD void fexp_stage1(const Fp12R& f, const FexpScratch& sc) { fexp_start_exp(fexp_glue1(f, sc), sc); }
+BLS_HD void fexp_stage2(const FexpScratch& sc) { fexp_start_exp(fexp_glue2(sc), sc); }
+BLS_HD void fexp_stage3(const FexpScratch& sc) { fexp_start_exp(fexp_glue3(sc), sc); }
+BLS_HD void fexp_stage4(const FexpScratch& sc) { fexp_start_exp(fexp_glue4(sc), sc); }
+BLS_HD void fexp_stage5(const FexpScratch& sc) { fexp_start_exp(fexp_glue5(sc), sc); }
 BLS_HD Fp12R fexp_stage6(const FexpScratch& sc) {
   return mul_call(fexp_finish_exp(sc), fx_get12(sc.ls, FX_W));
 }

@@ -72,6 +72,16 @@ k_fexp_stage(const uint64_t* in, uint64_t* out, uint8_t* flags, uint32_t* __rest
   }
 }
 
+// The squaring chain alone (split launch, after k_fexp_glue*_wide parked its input): 178 registers, no scratch.
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_fexp_chain(uint32_t* __restrict__ scratch, uint32_t* __restrict__ norm_raw, size_t n, size_t lanes) {
+  const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gl / LANES_PER_ELEM;
+  if (i >= n) return;
+  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  fexp_chain(fx_getx(sc.ls), sc);
+}
+
 namespace bls_launch {
 size_t fexp_stage_scratch_bytes(size_t n_chunk) {      // for a chunk of n_chunk elements, any supported block size
   const size_t lanes = (n_chunk * bls::LANES_PER_ELEM + BLS_MAX_BLOCK - 1) / BLS_MAX_BLOCK * BLS_MAX_BLOCK;
@@ -94,26 +104,25 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
     auto after = [&](int k) { if (first == 0 && record_after && record_after[k]) (void)hipEventRecord(record_after[k], s); };
     hipLaunchKernelGGL(k_fexp_norm, grid, blk, 0, s, ci, raw_scratch, m, form);
     fp_batch_inv_raw(raw_scratch, m, s);
-    before(0);
-    hipLaunchKernelGGL(k_fexp_stage<1>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
-    after(0);
-    fp_batch_inv_raw(raw_scratch, m, s);
-    before(1);
-    hipLaunchKernelGGL(k_fexp_stage<2>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
-    after(1);
-    fp_batch_inv_raw(raw_scratch, m, s);
-    before(2);
-    hipLaunchKernelGGL(k_fexp_stage<3>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
-    after(2);
-    fp_batch_inv_raw(raw_scratch, m, s);
-    before(3);
-    hipLaunchKernelGGL(k_fexp_stage<4>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
-    after(3);
-    fp_batch_inv_raw(raw_scratch, m, s);
-    before(4);
-    hipLaunchKernelGGL(k_fexp_stage<5>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);
-    after(4);
-    fp_batch_inv_raw(raw_scratch, m, s);
+    // stages 1..5: glue + squaring chain, fused in one two-wave kernel or as a one-wave glue kernel plus the chain kernel
+    static const bool fused = getenv("BLS381_FEXP_FUSED_STAGES") != nullptr;    // A/B switch (tools/collect_profile.sh)
+    for (int st = 1; st <= 5; ++st) {
+      before(st - 1);
+      if (fused) {
+        switch (st) {
+          case 1: hipLaunchKernelGGL(k_fexp_stage<1>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form); break;
+          case 2: hipLaunchKernelGGL(k_fexp_stage<2>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form); break;
+          case 3: hipLaunchKernelGGL(k_fexp_stage<3>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form); break;
+          case 4: hipLaunchKernelGGL(k_fexp_stage<4>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form); break;
+          default: hipLaunchKernelGGL(k_fexp_stage<5>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form); break;
+        }
+      } else {
+        fexp_glue_wide(st, ci, stage_scratch, raw_scratch, m, lanes, form, block, s);
+        hipLaunchKernelGGL(k_fexp_chain, grid, blk, 0, s, stage_scratch, raw_scratch, m, lanes);
+      }
+      after(st - 1);
+      fp_batch_inv_raw(raw_scratch, m, s);
+    }
     before(5);
     static const bool narrow6 = getenv("BLS381_NARROW_STAGE6") != nullptr;      // A/B switch (tools/collect_profile.sh)
     if (narrow6) hipLaunchKernelGGL(k_fexp_stage<6>, grid, blk, 0, s, ci, co, cf, stage_scratch, raw_scratch, m, lanes, form);

@@ -26,6 +26,8 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
                       uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
                       const hipEvent_t* wait_before, const hipEvent_t* record_after);
 // stage 6 of the staged form compiled for one wave per SIMD (k_fexp_wide.hip); same arguments as the stage kernels
+// glue of stage 1..5 compiled for one wave per SIMD (split launch: followed by k_fexp_chain); `in` is read by stage 1 only
+void fexp_glue_wide(int stage, const uint64_t* in, uint32_t* scratch, uint32_t* norm_raw, size_t n, size_t lanes, int form, int block, hipStream_t s);
 void fexp_stage6_wide(uint64_t* out, uint8_t* flags, uint32_t* scratch, uint32_t* norm_raw, size_t n, size_t lanes, int form, int block, hipStream_t s);
 void fp_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);
 void fp2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int form, int block, hipStream_t s);

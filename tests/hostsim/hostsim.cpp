@@ -141,13 +141,26 @@ static void batch_inv_raw(uint32_t* raw, size_t n) {
 
 // The staged final exponentiation (fexp_stages.cuh) as the GPU runs it: norm pass, then six stages with a simultaneous
 // inversion before each; every stage runs over the whole batch before the next one starts, all state in scratch.
-static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n) {
+// split = true: every stage as the glue pass (parks the chain input) followed by the chain pass, like the library's default launch
+static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n, bool split = false) {
   uint32_t* raw = (uint32_t*)calloc(n ? n : 1, RAW_FP_STRIDE * sizeof(uint32_t));
   uint32_t* scratch = (uint32_t*)calloc((n ? n : 1) * (size_t)FX_DWORDS_PER_LANE, sizeof(uint32_t));
   if (!raw || !scratch) return 2;
   auto sc = [&](size_t i) { return FexpScratch{LaneScratch{scratch, n, i}, raw, i}; };
   for (size_t i = 0; i < n; ++i) raw_fp_store(raw + i * RAW_FP_STRIDE, fp12_inv_norm_call(fp12_load(a + 72 * i, form)));
   batch_inv_raw(raw, n);
+  if (split) {
+    for (int st = 1; st <= 5; ++st) {
+      for (size_t i = 0; i < n; ++i) {
+        const FexpScratch c = sc(i);
+        const Fp12R x = st == 1 ? fexp_glue1(fp12_load(a + 72 * i, form), c) : st == 2 ? fexp_glue2(c) : st == 3 ? fexp_glue3(c)
+                      : st == 4 ? fexp_glue4(c) : fexp_glue5(c);
+        fx_putx(c.ls, compress(x));
+      }
+      for (size_t i = 0; i < n; ++i) { const FexpScratch c = sc(i); fexp_chain(fx_getx(c.ls), c); }
+      batch_inv_raw(raw, n);
+    }
+  } else {
   for (size_t i = 0; i < n; ++i) fexp_stage1(fp12_load(a + 72 * i, form), sc(i));
   batch_inv_raw(raw, n);
   for (size_t i = 0; i < n; ++i) fexp_stage2(sc(i));
@@ -158,6 +171,7 @@ static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n
   batch_inv_raw(raw, n);
   for (size_t i = 0; i < n; ++i) fexp_stage5(sc(i));
   batch_inv_raw(raw, n);
+  }
   for (size_t i = 0; i < n; ++i) fp12_store(out + 72 * i, fexp_stage6(sc(i)), form);
   free(raw); free(scratch);
   return 0;
@@ -166,6 +180,7 @@ static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n
 int hostsim_fp12_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   if (op == OP12_FINAL_EXP_SPLIT) return final_exp_split(form, a, out, n);
   if (op == 9) return final_exp_staged(form, a, out, n);
+  if (op == 12) return final_exp_staged(form, a, out, n, true);
   for (size_t i = 0; i < n; ++i) {
     Fp12R x = fp12_load(a + 72 * i, form);
     Fp12R y = b ? fp12_load(b + 72 * i, form) : x;

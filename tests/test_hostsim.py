@@ -108,6 +108,7 @@ def test_final_exp_staged_with_compressed_squarings(hostsim):
     X = enc_fp12s(vals)
     exp = [O.final_exponentiation(v) or zero for v in vals]
     assert dec_fp12s(hostsim.fp12_op(9, X)) == exp
+    assert dec_fp12s(hostsim.fp12_op(12, X)) == exp          # glue and chain as separate passes (the default launch)
     for n in (1, 3):
         assert dec_fp12s(hostsim.fp12_op(9, X[:72 * n])) == exp[:n], n
 
