@@ -12,7 +12,7 @@ dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
 # one bench step = one launch of each ("k_final_exp" also matches k_final_exp_given; only one of the two runs)
-KERNELS = ("k_multi_miller", "k_fexp_norm", "k_fp_batch_inv", "k_final_exp", "k_fexp_stage")
+KERNELS = ("k_multi_miller", "k_fexp_norm", "k_fp_batch_inv", "k_final_exp", "k_fexp_stage", "k_fexp_glue", "k_fexp_chain")
 
 
 def counters(path):
