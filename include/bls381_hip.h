@@ -69,13 +69,13 @@ enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_B
           (what arkworks' affine types hold); for other coordinate values only 0 reproduces the reference's arithmetic.
           Miller-only entry points always follow Alg. 26/27. */,
        BLS381_OPT_FEXP_CHUNK_LOG2 = 6 /* staged final exponentiation: a batch of more than 2^value elements runs in passes of 2^value
-          (10..22, default 20: ~8.9 GB of stage scratch).  Lower it to cap the scratch; the tests lower it to run the multi-pass path. */ };
+          (10..22, default 20: ~7.0 GB of stage scratch).  Lower it to cap the scratch; the tests lower it to run the multi-pass path. */ };
 enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per element */
        BLS381_FEXP_BATCHED_INVERSION = 1, /* the Fp inversion under f^-1 (:175) from a batch-wide simultaneous inversion: three launches,
                                              64 B of context-owned device scratch per element */
        BLS381_FEXP_STAGED = 2,          /* additionally Karabina-compressed cyclotomic squarings, their decompression denominators
                                              inverted batch-wide: six stage kernels with an inversion kernel before each,
-                                             ~8.5 KB of context-owned device scratch per element (batches above 2^20 elements
+                                             ~6.7 KB of context-owned device scratch per element (batches above 2^20 elements
                                              run in passes of 2^20) */
        BLS381_FEXP_AUTO = 3,            /* STAGED for batches of at least 2^19 elements (where it wins: 294 vs 303 ms at 2^20, even at
                                              2^19, 3 % behind at 2^18), BATCHED_INVERSION below, and for a call whose stage
