@@ -77,8 +77,9 @@ enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per 
                                              inverted batch-wide: six stage kernels with an inversion kernel before each,
                                              ~6.7 KB of context-owned device scratch per element (batches above 2^20 elements
                                              run in passes of 2^20) */
-       BLS381_FEXP_AUTO = 3,            /* STAGED for batches of at least 2^19 elements (where it wins: 294 vs 303 ms at 2^20, even at
-                                             2^19, 3 % behind at 2^18), BATCHED_INVERSION below, and for a call whose stage
+       BLS381_FEXP_AUTO = 3,            /* STAGED for batches of at least 2^17 elements (final exponentiation alone: 21.2 vs 21.8 ms at
+                                             2^17, 36.7 vs 42.0 at 2^18, 132.9 vs 162.1 at 2^20; 13.5 vs 11.9 at 2^16), BATCHED_INVERSION
+                                             below, and for a call whose stage
                                              scratch cannot be allocated */
        BLS381_FEXP_DEFAULT = BLS381_FEXP_AUTO };
 enum { BLS381_IO_ARK_MONT = 0, BLS381_IO_CANONICAL = 1 };

@@ -217,7 +217,8 @@ struct Timed {
 // asynchronous, so a previous call may still be using the buffers: on the same stream the order is implicit; after
 // bls381_set_stream the new stream first waits for the event recorded behind the last user; an outgrown buffer is released
 // only after that user has finished.
-constexpr size_t FEXP_AUTO_STAGED_MIN = (size_t)1 << 19; // BLS381_FEXP_AUTO: staged form from this batch size on
+constexpr size_t FEXP_AUTO_STAGED_MIN = (size_t)1 << 17; // BLS381_FEXP_AUTO: staged form from this batch size on (tools/time_fexp_modes.py:
+                                                         // 2^16: 13.5 vs 11.9 ms, 2^17: 21.2 vs 21.8, 2^18: 36.7 vs 42.0, 2^20: 132.9 vs 162.1)
 constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14; // staged form: from this many elements on, two half-batch pipelines
 
 struct FexpPlan { uint32_t* raw = nullptr; uint32_t* stage = nullptr; size_t chunk = 0; };

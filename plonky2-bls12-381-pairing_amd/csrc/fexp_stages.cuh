@@ -87,9 +87,10 @@ BLS_HD Fp12R decompress(const Fp12C& g, const Fp2R& den_inv) {
     num = fit<1, 2>(sub(add(mul_xi(sqr(g.z5)), add(dbl(s4), s4)), dbl(g.z3)));
   }
   const Fp2R z1 = mul(num, den_inv);
-  const Fp2R m34 = mul(g.z3, g.z4);
-  const auto inner = sub(add(dbl(sqr(z1)), mul(g.z2, g.z5)), add(dbl(m34), m34));
-  const Fp2R z0 = fit<1, 2>(add(mul_xi(fit<1, 2>(inner)), fp2_one()));
+  // 2 z1^2 + z2 z5 - 3 z3 z4 as one lazy sum (fp.cuh dot): five Fp products and one reduction per lane instead of 1 + 2 + 2 and three
+  const auto m3z3 = neg(add(dbl(g.z3), g.z3));                 // limb bounds of the three products add up to exactly 17 (fp.cuh)
+  const Fp2R inner = dot2(pr2(dbl(z1), z1), pr2(g.z2, g.z5), pr2(m3z3, g.z4));
+  const Fp2R z0 = fit<1, 2>(add(mul_xi(inner), fp2_one()));
   return Fp12R(Fp6R(z0, g.z4, g.z3), Fp6R(g.z2, z1, g.z5));
 }
 
@@ -194,9 +195,22 @@ BLS_HD Fp12R frobenius_n(const Fp12R& a, int n) {
 // Each stage = its glue (Fq12 products around the exponentiation just finished; returns the value whose exponentiation starts
 // next) followed by that value's squaring chain.  The two halves can run fused in one kernel (k_fexp_stage<i>, two waves per
 // SIMD) or as two launches with the glue compiled for one wave per SIMD (k_fexp_glue + k_fexp_chain, k_fexp_wide.hip / k_fexp.hip).
+// The pass in front of stage 1: the Fp norm under f^-1 (fq12_target_tree.rs:77-90 bottoms out in one Fp inversion) for the batch
+// inversion, and the four Fp2 values of the inversion that stage 1 needs again, parked in the (not yet used) chain-input slots
+// instead of being recomputed (~9 400 multiply-adds per lane).
+BLS_HD FpR fexp_norm_pass(const Fp12R& f, const LaneScratch& ls) {
+  Fp6InvState st;
+  const FpR nrm = fp12_inv_begin(f, st);
+  fp2_scratch_put(ls, FX_X_BASE + 0, st.c0); fp2_scratch_put(ls, FX_X_BASE + 1, st.c1);
+  fp2_scratch_put(ls, FX_X_BASE + 2, st.c2); fp2_scratch_put(ls, FX_X_BASE + 3, st.t);
+  return nrm;
+}
 BLS_HD Fp12R fexp_glue1(const Fp12R& f, const FexpScratch& sc) {
   const FpR f_norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
-  const Fp12R f_inv = fp12_inv_given_call(f, f_norm_inv);
+  Fp6InvState st;
+  st.c0 = fp2_scratch_get(sc.ls, FX_X_BASE + 0); st.c1 = fp2_scratch_get(sc.ls, FX_X_BASE + 1);
+  st.c2 = fp2_scratch_get(sc.ls, FX_X_BASE + 2); st.t = fp2_scratch_get(sc.ls, FX_X_BASE + 3);
+  const Fp12R f_inv = fp12_inv_end(f, st, f_norm_inv);
   Fp12R m = mul_call(fit<1, 2>(conj(f)), f_inv);                        // :168-175, :133
   m = mul_call(frobenius_n(m, 2), m);                                   // :135-136
   fx_put12(sc.ls, FX_M, m);

@@ -72,6 +72,16 @@ k_fexp_stage(const uint64_t* in, uint64_t* out, uint8_t* flags, uint32_t* __rest
   }
 }
 
+// Norm pass of the staged form: like k_fexp_norm, and parks the intermediate values of the inversion for stage 1 (fexp_norm_pass)
+__global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_fexp_norm_park(const uint64_t* __restrict__ in, uint32_t* __restrict__ scratch, uint32_t* __restrict__ raw, size_t n, size_t lanes, int form) {
+  const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gl / LANES_PER_ELEM;
+  if (i >= n) return;
+  const FpR nrm = fexp_norm_pass(fp12_load(in + 72 * i, form), LaneScratch{scratch, lanes, gl});
+  if (lane_part() == 0) raw_fp_store(raw + i * RAW_FP_STRIDE, nrm);
+}
+
 // The squaring chain alone (split launch, after k_fexp_glue*_wide parked its input): 178 registers, no scratch.
 __global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_fexp_chain(uint32_t* __restrict__ scratch, uint32_t* __restrict__ norm_raw, size_t n, size_t lanes) {
@@ -102,7 +112,7 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
     // events tie the stage kernels of the first pass to another pipeline's (see bls381_hip.hip)
     auto before = [&](int k) { if (first == 0 && wait_before && wait_before[k]) (void)hipStreamWaitEvent(s, wait_before[k], 0); };
     auto after = [&](int k) { if (first == 0 && record_after && record_after[k]) (void)hipEventRecord(record_after[k], s); };
-    hipLaunchKernelGGL(k_fexp_norm, grid, blk, 0, s, ci, raw_scratch, m, form);
+    hipLaunchKernelGGL(k_fexp_norm_park, grid, blk, 0, s, ci, stage_scratch, raw_scratch, m, lanes, form);
     fp_batch_inv_raw(raw_scratch, m, s);
     // stages 1..5: glue + squaring chain, fused in one two-wave kernel or as a one-wave glue kernel plus the chain kernel
     static const bool fused = getenv("BLS381_FEXP_FUSED_STAGES") != nullptr;    // A/B switch (tools/collect_profile.sh)

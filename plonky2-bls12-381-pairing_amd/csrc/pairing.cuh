@@ -21,6 +21,9 @@
 
 // Hook at the top of every Miller-loop iteration (experiments: e.g. a workgroup barrier that keeps the waves of a CU
 // within one iteration of each other so that they share instruction-cache lines).  Empty by default.
+#ifndef BLS_MILLER_PEEL          // 1: the first line of a Miller loop is copied into f instead of multiplied into f = 1
+#define BLS_MILLER_PEEL 1
+#endif
 #ifndef BLS_MILLER_ITERATION_HOOK
 #define BLS_MILLER_ITERATION_HOOK() ((void)0)
 #endif
@@ -374,6 +377,11 @@ BLS_HD Fp12R ell(const Fp12R& f, const LineCoeffs& l, const G1Aff& p) {
   const Fp2R c1 = mul_fp(l.b, p.x);
   return mul_by_014(f, l.c, c1, c0);
 }
+// ell(1, l, p): the line itself as a (sparse) Fq12 value -- what the first step of a Miller loop multiplies into f = 1
+BLS_HD Fp12R line_value(const LineCoeffs& l, const G1Aff& p) {
+  const Fp2R z = Fp2R(fp2_zero());
+  return Fp12R(Fp6R(l.c, mul_fp(l.b, p.x), z), Fp6R(z, mul_fp(l.a, p.y), z));
+}
 BLS_HD_NOINLINE LineCoeffs doubling_step_call(G2Jac& r) { return doubling_step(r); }
 BLS_HD_NOINLINE LineCoeffs addition_step_call(G2Jac& r, const G2Aff& q) { return addition_step(r, q); }
 BLS_HD_NOINLINE LineCoeffs doubling_step_hom_call(G2Jac& r) { return doubling_step_hom(r); }
@@ -406,7 +414,8 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
         for (int j = 0; j < N_PAIRS; ++j) {
           const LineCoeffs l = HOM ? ((pass == 0) ? doubling_step_hom(r[j]) : addition_step_hom(r[j], q[j]))
                                    : ((pass == 0) ? doubling_step(r[j]) : addition_step(r[j], q[j]));
-          if (!skip[j]) f = ell(f, l, p[j]);
+          // the very first line meets f = 1: no multiplication (a uniform branch; a skipped first pair leaves f = 1 for the next)
+          if (!skip[j]) f = (BLS_MILLER_PEEL && b == 61 && pass == 0 && j == 0) ? line_value(l, p[j]) : ell(f, l, p[j]);
         }
       } else {
 #pragma unroll

@@ -268,6 +268,9 @@ BLS_FN_FP12 Fp12R frobenius(const Fp12<L, V>& a) {
 #ifndef BLS_LAZY_014
 #define BLS_LAZY_014 0
 #endif
+#ifndef BLS_LAZY_014_ORDER      // order in which the six coefficients are computed (register pressure; tools/kbench A/B)
+#define BLS_LAZY_014_ORDER 0
+#endif
 template <int L, int V, int L0, int V0, int L1, int V1, int L4, int V4>
 BLS_HD Fp12R mul_by_014_lazy(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const Fp2<L1, V1>& c1, const Fp2<L4, V4>& c4) {
   const auto xc1 = fit<1, 64>(mul_xi(c1));
@@ -275,6 +278,7 @@ BLS_HD Fp12R mul_by_014_lazy(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const F
   const auto& f00 = f.c0.c0; const auto& f01 = f.c0.c1; const auto& f02 = f.c0.c2;
   const auto& f10 = f.c1.c0; const auto& f11 = f.c1.c1; const auto& f12 = f.c1.c2;
   Fp12R r;
+#if BLS_LAZY_014_ORDER == 0
   // the three coefficients that read xi c1 / xi c4 first, then the three that read c4: four line operands live at a time
   r.c0.c0 = dot2(pr2(c0, f00), pr2(xc1, f02), pr2(xc4, f11));
   r.c1.c0 = dot2(pr2(c0, f10), pr2(xc1, f12), pr2(xc4, f02));
@@ -282,6 +286,14 @@ BLS_HD Fp12R mul_by_014_lazy(const Fp12<L, V>& f, const Fp2<L0, V0>& c0, const F
   r.c0.c2 = dot2(pr2(c1, f01), pr2(c0, f02), pr2(c4, f10));
   r.c1.c1 = dot2(pr2(c1, f10), pr2(c0, f11), pr2(c4, f00));
   r.c1.c2 = dot2(pr2(c1, f11), pr2(c0, f12), pr2(c4, f01));
+#else
+  r.c0.c0 = dot2(pr2(c0, f00), pr2(xc1, f02), pr2(xc4, f11));
+  r.c0.c1 = dot2(pr2(c1, f00), pr2(c0, f01), pr2(xc4, f12));
+  r.c0.c2 = dot2(pr2(c1, f01), pr2(c0, f02), pr2(c4, f10));
+  r.c1.c0 = dot2(pr2(c0, f10), pr2(xc1, f12), pr2(xc4, f02));
+  r.c1.c1 = dot2(pr2(c1, f10), pr2(c0, f11), pr2(c4, f00));
+  r.c1.c2 = dot2(pr2(c1, f11), pr2(c0, f12), pr2(c4, f01));
+#endif
   return r;
 }
 

@@ -395,9 +395,9 @@ def test_staged_fexp_above_one_chunk_full_size(engine, coracle, pools):
     assert _oracle_sample(coracle, g1, g2, out, n, 1024)
 
 
-@pytest.mark.parametrize("n", [(1 << 19) - 64, 1 << 19])
+@pytest.mark.parametrize("n", [(1 << 17) - 64, 1 << 17])
 def test_fexp_auto_both_sides_of_the_switch(engine, coracle, pools, n):
-    """BLS381_FEXP_AUTO picks the batched-inversion form below 2^19 elements and the staged form from 2^19 on."""
+    """BLS381_FEXP_AUTO picks the batched-inversion form below 2^17 elements and the staged form from 2^17 on."""
     from bls381_amd import synthetic
     g1, g2 = synthetic.mirrored_affine_batch(pools, n, first=777)
     out, fl = engine.multi_pairing(g1, g2, 1)
