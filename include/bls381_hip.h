@@ -100,7 +100,11 @@ enum { BLS381_FP6_ADD = 0, BLS381_FP6_SUB = 1, BLS381_FP6_MUL = 2, BLS381_FP6_SQ
        BLS381_FP6_MUL_BY_NONRESIDUE = 6 /* x v */, BLS381_FP6_FROBENIUS = 7, BLS381_FP6_MUL_BY_01 = 8, BLS381_FP6_MUL_BY_1 = 9 };
 /* Fp12 ops */
 enum { BLS381_FP12_MUL = 0, BLS381_FP12_SQR = 1, BLS381_FP12_INV = 2, BLS381_FP12_FROBENIUS = 3,
-       BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6 };
+       BLS381_FP12_CYCLOTOMIC_SQR = 4, BLS381_FP12_CONJ = 5, BLS381_FP12_CYCLOTOMIC_EXP = 6,
+       BLS381_FP12_MUL_BY_014 = 7 /* sparse line multiplication (commented `mul_by_014`, src/miller_loop_native.rs:118-137; live twin
+          src/fields_as_trees/fq12_target_tree.rs:157-176): a * (c0, c1, 0 | 0, c4, 0) with (c0, c1, c4) read from b's slots c0.c0, c0.c1,
+          c1.c1 -- in the form the Miller kernels run it (six lazy three-product sums, one reduction each) */,
+       BLS381_FP12_MUL_BY_014_KARATSUBA = 8 /* the same value by Karatsuba over Fq6 as the reference writes it */ };
 
 /* Point ops on Jacobian points (arkworks `Projective`: x = X/Z^2, y = Y/Z^3; Z = 0 is the point at infinity) */
 enum { BLS381_POINT_ADD = 0        /* ark-ec 0.4.2 `Projective += &Projective` (add-2007-bl with the equal -> double and

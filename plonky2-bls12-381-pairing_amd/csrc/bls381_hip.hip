@@ -556,7 +556,7 @@ int bls381_fp6_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t
 }
 
 int bls381_fp12_op_batch(bls381_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  if (!c || op < 0 || op > BLS381_FP12_CYCLOTOMIC_EXP || (n && (!a || !out))) return BLS381_E_INVALID;
+  if (!c || op < 0 || op > BLS381_FP12_MUL_BY_014_KARATSUBA || (n && (!a || !out))) return BLS381_E_INVALID;
   if (op == BLS381_FP12_MUL && n && !b) return BLS381_E_INVALID;
   if (n == 0) return BLS381_OK;
   return with_staging(c, a, n * 576, b, b ? n * 576 : 0, out, n * 576, nullptr, n,

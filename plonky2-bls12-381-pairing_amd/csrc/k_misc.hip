@@ -49,6 +49,11 @@ k_fp12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n,
     case BLS381_FP12_CYCLOTOMIC_SQR: r = cyclotomic_square(x); break;
     case BLS381_FP12_CONJ: r = fit<1, 2>(conj(x)); break;
     case BLS381_FP12_CYCLOTOMIC_EXP: r = cyclotomic_exp(x); break;
+    case BLS381_FP12_MUL_BY_014: case BLS381_FP12_MUL_BY_014_KARATSUBA: {      // sparse factor (c0, c1, c4) = (b.c0.c0, b.c0.c1, b.c1.c1)
+      const Fp12R y = b ? fp12_load(b + 72 * i, form) : x;
+      r = (op == BLS381_FP12_MUL_BY_014) ? mul_by_014_lazy(x, y.c0.c0, y.c0.c1, y.c1.c1) : mul_by_014(x, y.c0.c0, y.c0.c1, y.c1.c1);
+      break;
+    }
     default: break;
   }
   fp12_store(out + 72 * i, r, form);

@@ -28,7 +28,7 @@ FLAG_NO_INVERSE, FLAG_NOT_SQUARE, FLAG_SIGN_UNSATISFIABLE = 4, 8, 16
 FP_ADD, FP_SUB, FP_MUL, FP_SQR, FP_INV, FP_NEG, FP_TO_MONT, FP_FROM_MONT, FP_DIV, FP_LEGENDRE, FP_IS_SQUARE, FP_SGN0 = range(12)
 FP2_ADD, FP2_SUB, FP2_MUL, FP2_SQR, FP2_INV, FP2_NEG, FP2_CONJ, FP2_MUL_BY_NONRESIDUE = range(8)
 FP6_ADD, FP6_SUB, FP6_MUL, FP6_SQR, FP6_INV, FP6_NEG, FP6_MUL_BY_NONRESIDUE, FP6_FROBENIUS, FP6_MUL_BY_01, FP6_MUL_BY_1 = range(10)
-FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP = range(7)
+FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP12_CYCLOTOMIC_EXP, FP12_MUL_BY_014, FP12_MUL_BY_014_KARATSUBA = range(9)
 
 # every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

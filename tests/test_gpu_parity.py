@@ -58,6 +58,23 @@ def test_tower_ops_golden(engine):
     assert dec_fp12s(engine.fp12_op(B.FP12_CYCLOTOMIC_EXP, X)) == [O.cyclotomic_exp(_fp12(c["x"])) for c in cases]
 
 
+def test_sparse_line_multiplication_both_forms(engine):
+    """mul_by_014 (fields_as_trees/fq12_target_tree.rs:157-176) as the Miller kernels run it -- six lazy three-product sums with one
+    reduction each -- and as Karatsuba over Fq6, against the oracle; zero, all-(p-1) and random operands, a ragged batch."""
+    import random
+    from blsutil import rand_fp12
+    rng = random.Random(1414)
+    n = 133
+    fs = [rand_fp12(rng) for _ in range(n)]
+    ys = [rand_fp12(rng) for _ in range(n)]
+    ys[3] = O.fp12_unflatten([0] * 12); fs[4] = O.fp12_unflatten([0] * 12)
+    fs[5] = O.fp12_unflatten([O.P - 1] * 12); ys[5] = O.fp12_unflatten([O.P - 1] * 12)
+    X = enc_fp12s(fs); Y = enc_fp12s(ys)
+    exp = [O.fp12_mul_by_014(f, y[0][0], y[0][1], y[1][1]) for f, y in zip(fs, ys)]
+    assert dec_fp12s(engine.fp12_op(B.FP12_MUL_BY_014, X, Y)) == exp
+    assert dec_fp12s(engine.fp12_op(B.FP12_MUL_BY_014_KARATSUBA, X, Y)) == exp
+
+
 def test_final_exp_modes_agree_with_the_oracle(engine):
     """BLS381_OPT_FEXP_MODE: the self-contained kernel, the split form (norm kernel, simultaneous inversion eight per lane,
     finishing kernel) and the staged form (Karabina-compressed squaring chains, six stages) give the oracle's bits, for
