@@ -1,5 +1,6 @@
 """GPU parity tests proper: the HIP path, called through the C ABI (libbls381_hip.so via ctypes), against the
 oracle and the committed golden fixtures -- bit-exact (integer arithmetic).  `pytest -m gpu` on an MI355X."""
+import os
 import random
 
 import numpy as np
@@ -134,6 +135,25 @@ def test_staged_fexp_pipelines(engine, coracle, pipes):
         assert np.array_equal(out, exp) and np.array_equal(fl, efl)
     finally:
         engine.set_option(B.OPT_FEXP_PIPELINES, default)
+
+
+def test_staged_fexp_fused_stage_launches(coracle, tmp_path):
+    """The A/B launch forms of the staged final exponentiation -- stages 1..5 as fused two-wave kernels
+    (BLS381_FEXP_FUSED_STAGES) and the two-wave stage 6 (BLS381_NARROW_STAGE6), read from the environment when the library
+    first launches a staged final exponentiation -- in a fresh process, against the oracle."""
+    import subprocess, sys
+    n = (1 << 14) + 77
+    g1, g2 = synthetic_batch(n, seed=4242, jacobian=False, pool=64)
+    exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
+    np.save(tmp_path / "g1.npy", g1); np.save(tmp_path / "g2.npy", g2)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import bls381_amd as B; e = B.Engine(0); "
+            "e.set_option(B.OPT_FEXP_MODE, B.FEXP_STAGED); "
+            "o, f = e.multi_pairing(np.load(%r), np.load(%r), 1); np.save(%r, o); np.save(%r, f)"
+            % (os.path.dirname(os.path.dirname(B.__file__)), str(tmp_path / "g1.npy"), str(tmp_path / "g2.npy"),
+               str(tmp_path / "out.npy"), str(tmp_path / "fl.npy")))
+    env = dict(os.environ, BLS381_FEXP_FUSED_STAGES="1", BLS381_NARROW_STAGE6="1")
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    assert np.array_equal(np.load(tmp_path / "out.npy"), exp) and np.array_equal(np.load(tmp_path / "fl.npy"), efl)
 
 
 def test_homogeneous_miller_option_domain(engine, coracle):
