@@ -147,7 +147,7 @@ def main(argv=None):
     if fexp_mode == B.FEXP_AUTO:
         fexp_mode = B.FEXP_STAGED if n_units >= (1 << 17) else B.FEXP_BATCHED_INVERSION
     fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
-                    "k_fexp_norm + 5 x (k_fp_batch_inv + k_fexp_glue*_wide + k_fexp_chain) + k_fp_batch_inv + k_fexp_stage6_wide, two half-batch pipelines")[fexp_mode]
+                    "k_fexp_norm_park + 5 x (k_fp_batch_inv + k_fexp_glue*_wide + k_fexp_chain) + k_fp_batch_inv + k_fexp_stage6_wide, two half-batch pipelines")[fexp_mode]
 
     jac = args.workload == "ref_opt"
     pools = synthetic.build_pools(eng, args.pool)                # on the GPU, with the library's point kernels
