@@ -248,9 +248,10 @@ from coracle import COracle  # noqa: E402,F401  (oracle/coracle.py: the C restat
 
 
 def synthetic_batch(n, seed=O.SEED, jacobian=False, k=1, pool=64):
-    """Seeded synthetic batch in ABI layout: pool points, element i picks pool entries by a
-    counter-based PRNG; Jacobian inputs get a per-element random representative.  Returns (g1, g2) uint64 arrays.
-    Built by tiling `pool` distinct encoded elements so that 2^20-element batches cost milliseconds."""
+    """Small seeded batch in ABI layout for the oracle-sized tests: `pool` (x k) DISTINCT seeded pairs (multiples of the
+    generators; Jacobian inputs with random representatives) tiled to n elements -- element i equals element i mod pool.
+    Returns (g1, g2) uint64 arrays.  The full-size tests and bench.py use bls381_amd/synthetic.py instead (SURVEY 8d:
+    4096-point pools built on the GPU, element i = (P[i mod 4096], Q[(i * 2654435761 >> 12) mod 4096]))."""
     base = random_pairs(pool * k, seed, jacobian=jacobian)
     if jacobian:
         g1 = enc_fps([c for P, Q in base for c in flat_g1_jac(P)])
