@@ -1,6 +1,6 @@
 // libbls381_hip.so -- the C ABI of include/bls381_hip.h (contexts, staging, launches; kernels live in k_*.hip).
 //
-// One pairing per lane pair (fp2_pair.cuh); a workgroup is `block` lanes (default one 64-lane wave = 32 pairings).  Each entry point cites
+// One pairing per lane pair (fp2_pair.hip.h); a workgroup is `block` lanes (default one 64-lane wave = 32 pairings).  Each entry point cites
 // the reference item it replaces in include/bls381_hip.h.  There is NO host fallback: without a HIP device
 // bls381_create fails with BLS381_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
@@ -27,7 +27,7 @@ struct bls381_ctx {
   int fexp_mode = BLS381_FEXP_DEFAULT;   // BLS381_OPT_FEXP_MODE
   uint32_t* raw_scratch = nullptr;   // n x 16 dwords: norms / norm inverses between the final-exponentiation kernels
   size_t raw_scratch_elems = 0;
-  uint32_t* stage_scratch = nullptr; // staged form: lane-sliced stage values (csrc/fexp_stages.cuh)
+  uint32_t* stage_scratch = nullptr; // staged form: lane-sliced stage values (csrc/fexp_stages.hip.h)
   size_t stage_scratch_bytes = 0;
   uint64_t* part_scratch = nullptr;  // products of more than four pairs: Miller value of the current group of pairs (n x 72 u64)
   size_t part_scratch_elems = 0;

@@ -25,9 +25,9 @@
 //   4  c = E(b) frob(b)               = b^(x+p);                                        start E(c)
 //   5  d1 = E(c);  W = frob^2(c) conj(c) (m^2 m);                                       start E(d1)
 //   6  result = E(d1) W               = c^(x^2+p^2-1) m^3
-// The one-kernel forms (tower.cuh final_exponentiation*) keep the reference's own chain; tests compare all of them.
+// The one-kernel forms (tower.hip.h final_exponentiation*) keep the reference's own chain; tests compare all of them.
 #pragma once
-#include "tower.cuh"
+#include "tower.hip.h"
 
 namespace bls {
 
@@ -35,7 +35,7 @@ struct Fp12C { Fp2R z2, z3, z4, z5; };       // compressed cyclotomic element
 
 BLS_HD Fp12C compress(const Fp12R& f) { return Fp12C{f.c1.c0, f.c0.c2, f.c0.c1, f.c1.c2}; }
 
-// The z2..z5 half of cyclotomic_square (tower.cuh).  Two forms with the same values:
+// The z2..z5 half of cyclotomic_square (tower.hip.h).  Two forms with the same values:
 //   BLS_CSQR_PRODUCTS = 0   verbatim: two Fp4 squarings = six Fp2 squarings
 //   BLS_CSQR_PRODUCTS = 1   z2^2 + xi z3^2 = (z2 + z3)(z2 + xi z3) - (1 + xi) z2 z3  and  2 z2 z3 from the same product:
 //                           four Fp2 multiplications.  Per lane the multiply-add count is the same (4 x 588 = 6 x 392), but
@@ -87,15 +87,15 @@ BLS_HD Fp12R decompress(const Fp12C& g, const Fp2R& den_inv) {
     num = fit<1, 2>(sub(add(mul_xi(sqr(g.z5)), add(dbl(s4), s4)), dbl(g.z3)));
   }
   const Fp2R z1 = mul(num, den_inv);
-  // 2 z1^2 + z2 z5 - 3 z3 z4 as one lazy sum (fp.cuh dot): five Fp products and one reduction per lane instead of 1 + 2 + 2 and three
-  const auto m3z3 = neg(add(dbl(g.z3), g.z3));                 // limb bounds of the three products add up to exactly 17 (fp.cuh)
+  // 2 z1^2 + z2 z5 - 3 z3 z4 as one lazy sum (fp.hip.h dot): five Fp products and one reduction per lane instead of 1 + 2 + 2 and three
+  const auto m3z3 = neg(add(dbl(g.z3), g.z3));                 // limb bounds of the three products add up to exactly 17 (fp.hip.h)
   const Fp2R inner = dot2(pr2(dbl(z1), z1), pr2(g.z2, g.z5), pr2(m3z3, g.z4));
   const Fp2R z0 = fit<1, 2>(add(mul_xi(inner), fp2_one()));
   return Fp12R(Fp6R(z0, g.z4, g.z3), Fp6R(g.z2, z1, g.z5));
 }
 
 // ------------------------------------------------------------------------------------------ scratch layout
-// Per element, in units of Fp2 values inside a LaneScratch (fp.cuh): three Fq12 slots, the six compressed powers of the
+// Per element, in units of Fp2 values inside a LaneScratch (fp.hip.h): three Fq12 slots, the six compressed powers of the
 // running exponentiation, and the prefix products of their denominators.
 enum : int { FX_M = 0, FX_A = 1, FX_W = 2, FX_SLOTS = 3 };     // m; a, then b, then c; W
 constexpr int FX_COMP_BASE = FX_SLOTS * 6;
@@ -161,7 +161,7 @@ BLS_HD void fexp_chain(const Fp12C& x, const FexpScratch& sc) {
 }
 BLS_HD_NOINLINE void fexp_start_exp(const Fp12R& x, const FexpScratch& sc) { fexp_chain(compress(x), sc); }
 
-// second half: conj(x^|x|) from the parked powers and the inverse of the norm (== cyclotomic_exp(x), tower.cuh)
+// second half: conj(x^|x|) from the parked powers and the inverse of the norm (== cyclotomic_exp(x), tower.hip.h)
 BLS_FN_COLD Fp12R fexp_finish_exp(const FexpScratch& sc) {
   const FpR norm_inv = raw_fp_load(sc.norm_raw + sc.elem * RAW_FP_STRIDE);
   // inverse of the product of all six denominators; peel one denominator per step, last power first

@@ -14,9 +14,9 @@
 // LDS).  Squaring is (a0+a1)(a0-a1) on the even lane and
 // (2 a0) a1 on the odd lane: one single-product multiplication each.
 //
-// Formulas: src/fields_as_trees/fq2_target_tree.rs:54-142 (reference).  Same API as fp2_serial.cuh.
+// Formulas: src/fields_as_trees/fq2_target_tree.rs:54-142 (reference).  Same API as fp2_serial.hip.h.
 #pragma once
-#include "fp.cuh"
+#include "fp.hip.h"
 
 namespace bls {
 
@@ -36,7 +36,7 @@ BLS_HD uint32_t dpp_swap(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
 #else
-  return x;   // host pass only type-checks this backend; the host simulation uses fp2_serial.cuh
+  return x;   // host pass only type-checks this backend; the host simulation uses fp2_serial.hip.h
 #endif
 }
 // c0 of the pair on both lanes / c1 of the pair on both lanes: DPP broadcasts inside each lane pair
@@ -139,7 +139,7 @@ BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   }
 }
 
-// Lazy sums of Fp2 products and squares (fp.cuh `dot_terms`): one reduction per lane for
+// Lazy sums of Fp2 products and squares (fp.hip.h `dot_terms`): one reduction per lane for
 //     dot2(pr2(A1, B1), sq2(A2), ...) = A1 B1 + A2^2 + ...
 // A product contributes the two Fp products of mul_raw on each lane -- even: a0 b0 + (-a1) b1 ; odd: a0 b1 + a1 b0 --, a square
 // the one of sqr -- even: (a0 + a1)(a0 - a1) ; odd: (2 a0) a1.

@@ -2,7 +2,7 @@
 // Used by the host simulation (tests/hostsim) and selectable on the GPU with -DBLS_LANES=1.
 // Formulas: src/fields_as_trees/fq2_target_tree.rs:54-142 (reference).
 #pragma once
-#include "fp.cuh"
+#include "fp.hip.h"
 
 namespace bls {
 
@@ -72,7 +72,7 @@ BLS_HD Fp2R mul(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   }
 }
 
-// Lazy sums of Fp2 products and squares (fp.cuh `dot_terms`): one reduction per coefficient for
+// Lazy sums of Fp2 products and squares (fp.hip.h `dot_terms`): one reduction per coefficient for
 //     dot2(pr2(A1, B1), sq2(A2), ...) = A1 B1 + A2^2 + ...
 template <class A, class B> struct Fp2Prod { const A& a; const B& b; };
 template <int La, int Va, int Lb, int Vb>

@@ -5,8 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "../../include/bls381_hip.h"
-#include "pairing.cuh"
-#include "fexp_stages.cuh"
+#include "pairing.hip.h"
+#include "fexp_stages.hip.h"
 #include "launch.h"
 using namespace bls;
 #ifndef BLS_MAX_BLOCK
@@ -51,7 +51,7 @@ k_final_exp_given(const uint64_t* in, uint64_t* out, uint8_t* flags, const uint3
   if (flags && lane_part() == 0) flags[i] = 0;
 }
 
-// Staged form (fexp_stages.cuh): Karabina-compressed squaring chains, one batch-wide inversion between stages.
+// Staged form (fexp_stages.hip.h): Karabina-compressed squaring chains, one batch-wide inversion between stages.
 // `lanes` = number of lanes of the launch (the lane-sliced scratch is laid out for exactly that many).
 template <int STAGE>
 __global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))

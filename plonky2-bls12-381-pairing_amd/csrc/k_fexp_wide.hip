@@ -5,8 +5,8 @@
 #include <hip/hip_runtime.h>
 #define BLS_COLD_INLINE 1
 #include "../../include/bls381_hip.h"
-#include "pairing.cuh"
-#include "fexp_stages.cuh"
+#include "pairing.hip.h"
+#include "fexp_stages.hip.h"
 #include "launch.h"
 using namespace bls;
 #ifndef BLS_MAX_BLOCK
@@ -40,7 +40,7 @@ k_fexp_glue_wide(int stage, uint32_t* __restrict__ scratch, uint32_t* __restrict
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
   const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
-  const Fp12R e = fexp_finish_exp(sc);                                   // E(previous value), fexp_stages.cuh
+  const Fp12R e = fexp_finish_exp(sc);                                   // E(previous value), fexp_stages.hip.h
   Fp12R x;
   if (stage == 5) {
     const Fp12R m = fx_get12(sc.ls, FX_M);

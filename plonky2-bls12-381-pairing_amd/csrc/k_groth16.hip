@@ -6,11 +6,11 @@
 // of three; every lane reads the shared coefficients as LDS broadcasts.
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
-// one wave per SIMD: every instruction costs one issue slot, so the sparse line multiplication runs as lazy sums (tower.cuh)
+// one wave per SIMD: every instruction costs one issue slot, so the sparse line multiplication runs as lazy sums (tower.hip.h)
 #ifndef BLS_LAZY_014
 #define BLS_LAZY_014 1
 #endif
-#include "pairing.cuh"
+#include "pairing.hip.h"
 #include "launch.h"
 using namespace bls;
 
@@ -80,7 +80,7 @@ k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ 
   if constexpr (NVAR == 1) { r.x = q0.x; r.y = q0.y; r.z = Fp2R(fp2_one()); }
   Fp12R f = fp12_one();
   int idx = 0;
-  for (int b = 61; b >= -1; --b) {             // same schedule as miller_ate (pairing.cuh)
+  for (int b = 61; b >= -1; --b) {             // same schedule as miller_ate (pairing.hip.h)
     const bool last = b < 0;
     const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {

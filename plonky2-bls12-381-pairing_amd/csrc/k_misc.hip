@@ -2,7 +2,7 @@
 // several TUs only to compile them in parallel; each exposes plain host launch functions (launch.h).
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
-#include "pairing.cuh"
+#include "pairing.hip.h"
 #include "launch.h"
 using namespace bls;
 #ifndef BLS_MAX_BLOCK

@@ -2,11 +2,11 @@
 // several TUs only to compile them in parallel; each exposes plain host launch functions (launch.h).
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
-// one wave per SIMD: every instruction costs one issue slot, so the sparse line multiplication runs as lazy sums (tower.cuh)
+// one wave per SIMD: every instruction costs one issue slot, so the sparse line multiplication runs as lazy sums (tower.hip.h)
 #ifndef BLS_LAZY_014
 #define BLS_LAZY_014 1
 #endif
-#include "pairing.cuh"
+#include "pairing.hip.h"
 #include "launch.h"
 using namespace bls;
 #ifndef BLS_MAX_BLOCK
@@ -19,7 +19,7 @@ static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bl
 #endif
 #define BLS_CAT2(a, b) a##b
 #define BLS_CAT(a, b) BLS_CAT2(a, b)
-// HOM: homogeneous-projective curve steps (pairing.cuh) -- for launches that are followed by the final exponentiation
+// HOM: homogeneous-projective curve steps (pairing.hip.h) -- for launches that are followed by the final exponentiation
 template <int K, bool HOM>
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
 k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2, size_t stride, uint64_t* __restrict__ out,

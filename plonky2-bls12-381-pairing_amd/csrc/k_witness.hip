@@ -1,7 +1,7 @@
-// Kernel translation unit: batched witness-generator backend (witness.cuh).
+// Kernel translation unit: batched witness-generator backend (witness.hip.h).
 #include <hip/hip_runtime.h>
 #include "../../include/bls381_hip.h"
-#include "witness.cuh"
+#include "witness.hip.h"
 #include "launch.h"
 using namespace bls;
 #ifndef BLS_MAX_BLOCK

@@ -18,7 +18,7 @@ void multi_k4(bool hom, const uint64_t*, const uint64_t*, size_t, uint64_t*, uin
 // raw_scratch: n x 16 dwords for the split form (batched inversion), or nullptr for the self-contained kernel
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);
 void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s);
-// staged form (Karabina-compressed squaring chains, csrc/fexp_stages.cuh): processes the batch in chunks of `chunk` elements;
+// staged form (Karabina-compressed squaring chains, csrc/fexp_stages.hip.h): processes the batch in chunks of `chunk` elements;
 // raw_scratch: chunk x 16 dwords, stage_scratch: fexp_stage_scratch_bytes(chunk) bytes; wait_before[k] / record_after[k]
 // (arrays of six, entries or the arrays may be null) are waited for before / recorded behind stage kernel k+1 of the first pass
 size_t fexp_stage_scratch_bytes(size_t n_chunk);

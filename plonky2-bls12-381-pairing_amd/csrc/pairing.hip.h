@@ -11,7 +11,7 @@
 //           src/miller_loop_native.rs:27-116 (+ commented `ell`, :118-152) specifies, and the final
 //           exponentiation of src/fields_as_trees/miller_loop.rs:128-178.
 #pragma once
-#include "tower.cuh"
+#include "tower.hip.h"
 
 // up to this many pairs the multi-pairing loop inlines one copy of the step routines per pair (state stays in
 // registers); beyond it the steps are calls

@@ -1,5 +1,5 @@
-// Fp6 -> Fp12 tower for the MI355X pairing engine, on top of an Fp2 backend (fp2_pair.cuh: one pairing per lane
-// pair, the GPU default; fp2_serial.cuh: one pairing per lane, used by the host build).
+// Fp6 -> Fp12 tower for the MI355X pairing engine, on top of an Fp2 backend (fp2_pair.hip.h: one pairing per lane
+// pair, the GPU default; fp2_serial.hip.h: one pairing per lane, used by the host build).
 //
 // Replaces the tower arithmetic the reference takes from ark-ff `Fq2/Fq6/Fq12` [third party]; formulas
 // follow the reference's written statements of the tower:
@@ -7,20 +7,20 @@
 //   Fp6  = Fp2[v]/(v^3-(1+u))   src/fields_as_trees/fq6_target_tree.rs:59-293
 //   Fp12 = Fp6[w]/(w^2-v)       src/fields_as_trees/fq12_target_tree.rs:53-176
 // Field values are canonical at the ABI, so only the algebraic value matters for bit-exactness; inside,
-// every Fp2 product is two fused multiply-pairs with a single Montgomery reduction each (fp.cuh) -- one per lane
+// every Fp2 product is two fused multiply-pairs with a single Montgomery reduction each (fp.hip.h) -- one per lane
 // of the pair in the lane-pair layout.
 //
-// Bounds <L, V> (limb / value, see fp.cuh) are carried through every type.  Functions whose results are
+// Bounds <L, V> (limb / value, see fp.hip.h) are carried through every type.  Functions whose results are
 // kept as loop state return "R" types (<1, 2>) by ending in fit<1, 2>().
 #pragma once
-#include "fp.cuh"
+#include "fp.hip.h"
 #ifndef BLS_LANES
 #define BLS_LANES 1
 #endif
 #if BLS_LANES == 2
-#include "fp2_pair.cuh"
+#include "fp2_pair.hip.h"
 #else
-#include "fp2_serial.cuh"
+#include "fp2_serial.hip.h"
 #endif
 
 // Inlining granularity of the tower (tunable: code size vs call traffic).  Serial backend: Fp2 products inline
@@ -259,7 +259,7 @@ BLS_FN_FP12 Fp12R frobenius(const Fp12<L, V>& a) {
 // sparse multiplication by (c0, c1, 0 | 0, c4, 0)   -- fq12_target_tree.rs:157-176 (commented twin at
 // src/miller_loop_native.rs:118-137)
 // BLS_LAZY_014 = 1: the same product written coefficient by coefficient as sums of three Fp2 products with ONE reduction
-// each (fp.cuh `dot`): 18 products / 6 reductions per lane instead of Karatsuba's 13 / 13, no pre/post additions and no final
+// each (fp.hip.h `dot`): 18 products / 6 reductions per lane instead of Karatsuba's 13 / 13, no pre/post additions and no final
 // conditioning (every coefficient leaves its reduction < 2p).  8 % more multiply-adds, ~15-19 % fewer instructions: a win where
 // every instruction costs the same issue slot (the Miller kernels, one wave per SIMD), not at two waves per SIMD.
 //   (f0 + f1 w)(A + B w),  A = c0 + c1 v,  B = c4 v,  w^2 = v,  v^3 = xi:

@@ -14,7 +14,7 @@
 // keep the one whose sgn0 equals the requested bit (src/fields/helpers.rs:159-174), so any correct root finder
 // gives identical bits.
 #pragma once
-#include "tower.cuh"
+#include "tower.hip.h"
 
 namespace bls {
 

@@ -130,7 +130,7 @@ def build_hostsim():
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
     so = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
     inc = os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "csrc")
-    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith((".cuh", ".h"))]
+    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith((".hip.h", ".h"))]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         import subprocess
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", inc, src, "-o", so])

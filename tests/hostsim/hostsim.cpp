@@ -1,14 +1,14 @@
 // TEST INFRASTRUCTURE -- not product code, never linked into libbls381_hip.so.
 //
-// Compiles the device headers (plonky2-bls12-381-pairing_amd/csrc/*.cuh) for the HOST with g++ and
+// Compiles the device headers (plonky2-bls12-381-pairing_amd/csrc/*.hip.h) for the HOST with g++ and
 // -DBLS_BOUND_CHECK so the `-m "not gpu"` suite can (1) check the kernels' algorithms against the oracle
 // without a GPU and (2) verify at run time every static limb/value bound the lazy-reduction types claim.
 // The product library has no CPU path: it fails loudly without a GPU.
 #define BLS_BOUND_CHECK 1
 #define BLS_LAZY_014 1      // the form the Miller kernels compile (k_multi.hip, k_groth16.hip); Karatsuba stays reachable as op 11
-#include "pairing.cuh"
-#include "witness.cuh"
-#include "fexp_stages.cuh"
+#include "pairing.hip.h"
+#include "witness.hip.h"
+#include "fexp_stages.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,7 +139,7 @@ static void batch_inv_raw(uint32_t* raw, size_t n) {
   }
 }
 
-// The staged final exponentiation (fexp_stages.cuh) as the GPU runs it: norm pass, then six stages with a simultaneous
+// The staged final exponentiation (fexp_stages.hip.h) as the GPU runs it: norm pass, then six stages with a simultaneous
 // inversion before each; every stage runs over the whole batch before the next one starts, all state in scratch.
 // split = true: every stage as the glue pass (parks the chain input) followed by the chain pass, like the library's default launch
 static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n, bool split = false) {

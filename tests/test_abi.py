@@ -49,7 +49,7 @@ def test_product_sources_never_touch_the_oracle():
         if os.sep + "build" in dirpath:
             continue
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp", "Makefile")):
+            if f.endswith((".py", ".hip", ".hip.h", ".h", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyref" not in txt and "bls381_oracle" not in txt and "hostsim" not in txt.replace("tests/hostsim", ""), os.path.join(dirpath, f)
 

@@ -63,7 +63,7 @@ def test_tower_golden(hostsim):
 
 
 def test_mul_by_014_lazy_sums_and_karatsuba(hostsim):
-    """The sparse line multiplication in the two forms of csrc/tower.cuh -- six three-product sums with one reduction each
+    """The sparse line multiplication in the two forms of csrc/tower.hip.h -- six three-product sums with one reduction each
     (what the Miller kernels compile) and Karatsuba over Fp6 -- against the oracle's mul_by_014
     (fields_as_trees/fq12_target_tree.rs:157-176), bound checks on."""
     rng = random.Random(14)
@@ -94,7 +94,7 @@ def test_final_exp_split_with_batched_inversion(hostsim):
 
 def test_final_exp_staged_with_compressed_squarings(hostsim):
     """The six-stage final exponentiation (Karabina-compressed squaring chains, their decompression denominators inverted
-    batch-wide between the stages; csrc/fexp_stages.cuh) gives the oracle's bits: random Fq12 inputs, the identity (whose
+    batch-wide between the stages; csrc/fexp_stages.hip.h) gives the oracle's bits: random Fq12 inputs, the identity (whose
     compressed form is all zero: the zero-denominator path), an element of GT, and a zero input (stays zero)."""
     rng = random.Random(78)
     vals = [rand_fp12(rng) for _ in range(10)]

@@ -191,7 +191,7 @@ def test_decompression_and_subgroup_oracle_round_trip():
 
 
 def test_hard_part_exponent_identity_of_the_staged_final_exponentiation():
-    """csrc/fexp_stages.cuh walks the hard part along (x - 1)^2 (x + p) (x^2 + p^2 - 1) + 3; the reference's chain
+    """csrc/fexp_stages.hip.h walks the hard part along (x - 1)^2 (x + p) (x^2 + p^2 - 1) + 3; the reference's chain
     (src/fields_as_trees/miller_loop.rs:137-163) reaches 3 (p^4 - p^2 + 1) / r.  Same integer, hence the same field element."""
     x = -O.BLS_X
     assert (O.P ** 4 - O.P ** 2 + 1) % O.R_ORDER == 0

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "pairing.cuh"
+#include "pairing.hip.h"
 using namespace bls;
 BLS_HD_NOINLINE LineCoeffs addition_step_hom_call(G2Jac& r, const G2Aff& q) { return addition_step_hom(r, q); }
 __global__ void k(const uint64_t* g2, uint64_t* out) {

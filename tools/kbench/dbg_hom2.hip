@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "pairing.cuh"
+#include "pairing.hip.h"
 using namespace bls;
 
 struct Dump {

@@ -12,7 +12,7 @@
 #ifdef KB_HOOK
 #define BLS_MILLER_ITERATION_HOOK() KB_HOOK
 #endif
-#include "pairing.cuh"
+#include "pairing.hip.h"
 using namespace bls;
 #ifndef KB_LB
 #define KB_LB 256

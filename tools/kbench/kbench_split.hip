@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "pairing.cuh"
+#include "pairing.hip.h"
 using namespace bls;
 #ifndef KB_ATTR_A
 #define KB_ATTR_A

@@ -1,8 +1,8 @@
-// Throughput of the Fp primitives of plonky2-bls12-381-pairing_amd/csrc/fp.cuh on gfx950, per SIMD and
+// Throughput of the Fp primitives of plonky2-bls12-381-pairing_amd/csrc/fp.hip.h on gfx950, per SIMD and
 // chip-wide, at 1/2/4 waves per SIMD.  Feeds DESIGN.md's integer roofline for the pairing kernels.
 //
 // build: hipcc -O3 --offload-arch=gfx950 -I../../plonky2-bls12-381-pairing_amd/csrc fp_bench.hip -o fp_bench
-#include "fp.cuh"
+#include "fp.hip.h"
 #include <cstdio>
 #include <vector>
 using namespace bls;
