@@ -210,8 +210,8 @@ BLS_HD FpR mul2(const Fp<La, Va>& a, const Fp<Lb, Vb>& b, const Fp<Lc, Vc>& c, c
 // scanning into 27 column accumulators (64-bit each: the same headroom argument as above, 14 * sum(La Lb) * 2^56 + 14 * 2^56
 // + carry < 2^64), so only ONE pair of operands has to be live at a time -- a column-scanning form of N products would
 // need all 2 N operands in registers at once.  Every reduction saved is 196 multiply-adds and ~120 other instructions;
-// at one wave per SIMD every instruction costs the same issue slot, so sparse tower products written as sums of
-// products (tower.hip.h: mul_by_014, mul_by_01) come out 12-15 % shorter than Karatsuba with a reduction per product.
+// at one wave per SIMD every instruction costs the same issue slot, so the sparse line multiplication written as six sums of
+// three products (tower.hip.h: mul_by_014_lazy) comes out 13 % shorter than Karatsuba with a reduction per product.
 BLS_HD void mont_acc_product(uint64_t (&acc)[2 * NL - 1], const uint32_t (&a)[NL], const uint32_t (&b)[NL]) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
