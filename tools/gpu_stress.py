@@ -50,7 +50,14 @@ out, fl = eng.multi_pairing(a, b, 1)
 assert np.array_equal(out, exp)
 print("mode B curve points ok", flush=True)
 x = np.frombuffer(np.random.default_rng(seed + 5).bytes(N * 576), dtype=np.uint64).copy(); x[5::6] &= np.uint64(0x0fffffffffffffff)
-assert np.array_equal(eng.final_exponentiation(x), orc.final_exp(x, threads=16))
+expx = orc.final_exp(x, threads=16)
+for mode in (B.FEXP_SELF_CONTAINED, B.FEXP_BATCHED_INVERSION, B.FEXP_STAGED, B.FEXP_AUTO):     # arbitrary (not unitary) Fq12 values
+    eng.set_option(B.OPT_FEXP_MODE, mode)
+    assert np.array_equal(eng.final_exponentiation(x), expx), ("final exponentiation", mode)
+eng.set_option(B.OPT_FEXP_MODE, B.FEXP_STAGED)
+out, fl = eng.multi_pairing(a, b, 1)
+assert np.array_equal(out, exp), "pairing, staged final exponentiation"
+eng.set_option(B.OPT_FEXP_MODE, B.FEXP_AUTO)
 for op in (0, 1, 2, 3, 4):
     assert np.array_equal(eng.fp12_op(op, x, x[::-1].copy() if False else x), orc.fp12_op(op, x, x)), op
 print("fp12 ok; ALL OK", flush=True)
