@@ -136,6 +136,9 @@ int bls381_last_hip_error(const bls381_ctx* ctx);
 /* Device time in ms of the most recent pairing / Miller-loop / final-exponentiation call on this context (every launch of the
  * call, between two HIP events recorded on the context's stream); waits for the call to finish; < 0 if there was none. */
 float bls381_last_kernel_ms(const bls381_ctx* ctx);
+/* The same call split at the boundary between its Miller loops (phase 0: the k_multi_miller / k_prepared_miller launches) and its
+ * final exponentiation (phase 1); < 0 when the most recent call was not a pairing / pairing-product call. */
+float bls381_last_phase_ms(const bls381_ctx* ctx, int phase);
 
 /* Mode A: optimized_miller_loop over a batch (src/miller_loop_native_optimized.rs:81).
  * g1_jac: n x 3 x 6 u64, g2_jac: n x 3 x 2 x 6, out_fq12: n x 12 x 6, flags: n bytes or NULL. */

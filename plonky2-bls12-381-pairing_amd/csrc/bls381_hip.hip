@@ -18,8 +18,8 @@ struct bls381_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the Miller loops and the final exponentiation
+  bool timed = false, timed_mid = false;
   int io_form = BLS381_IO_ARK_MONT;
   int fp2_shortcut = 0;
   int block = 64;
@@ -82,7 +82,7 @@ int bls381_create(bls381_ctx** out, int device_id) {
   if (!c) return BLS381_E_NOMEM;
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess ||
       hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->part_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) {
@@ -112,6 +112,7 @@ void bls381_destroy(bls381_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->raw_scratch) (void)hipFree(c->raw_scratch);
   if (c->stage_scratch) (void)hipFree(c->stage_scratch);
@@ -202,6 +203,14 @@ float bls381_last_kernel_ms(const bls381_ctx* c) {
   return ms;
 }
 
+float bls381_last_phase_ms(const bls381_ctx* c, int phase) {
+  if (!c || !c->timed || !c->timed_mid || phase < 0 || phase > 1) return -1.0f;
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+  float ms = -1.0f;
+  const hipError_t e = phase == 0 ? hipEventElapsedTime(&ms, c->ev0, c->ev_mid) : hipEventElapsedTime(&ms, c->ev_mid, c->ev1);
+  return e == hipSuccess ? ms : -1.0f;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------ launches
@@ -209,7 +218,7 @@ namespace {
 
 struct Timed {
   bls381_ctx* c;
-  explicit Timed(bls381_ctx* c_) : c(c_) { (void)hipEventRecord(c->ev0, c->stream); }
+  explicit Timed(bls381_ctx* c_) : c(c_) { c->timed_mid = false; (void)hipEventRecord(c->ev0, c->stream); }
   ~Timed() { (void)hipEventRecord(c->ev1, c->stream); c->timed = true; }
 };
 
@@ -350,7 +359,10 @@ int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k
       c->part_stream = c->stream;
       c->part_used = true;
     }
-    if (FE) rc = fexp_launch(c, plan, out, out, nullptr, n);
+    if (FE) {
+      c->timed_mid = hipEventRecord(c->ev_mid, c->stream) == hipSuccess;      // bls381_last_phase_ms: Miller loops | final exponentiation
+      rc = fexp_launch(c, plan, out, out, nullptr, n);
+    }
   }
   if (rc != BLS381_OK) return rc;
   HIP_TRY(c, hipGetLastError());
@@ -594,6 +606,7 @@ int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, con
     Timed t(c);
     if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
       return BLS381_E_INVALID;
+    c->timed_mid = hipEventRecord(c->ev_mid, c->stream) == hipSuccess;
     rc = fexp_launch(c, plan, out_gt, out_gt, nullptr, n);
   }
   if (rc != BLS381_OK) return rc;

@@ -33,7 +33,7 @@ FP12_MUL, FP12_SQR, FP12_INV, FP12_FROBENIUS, FP12_CYCLOTOMIC_SQR, FP12_CONJ, FP
 # every symbol include/bls381_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bls381_create", "bls381_destroy", "bls381_set_option", "bls381_get_option", "bls381_set_stream", "bls381_use_own_stream",
-    "bls381_sync", "bls381_strerror", "bls381_last_hip_error", "bls381_last_kernel_ms",
+    "bls381_sync", "bls381_strerror", "bls381_last_hip_error", "bls381_last_kernel_ms", "bls381_last_phase_ms",
     "bls381_miller_ref_opt_batch", "bls381_miller_ref_opt_batch_dev",
     "bls381_multi_miller_batch", "bls381_multi_miller_batch_dev",
     "bls381_multi_pairing_batch", "bls381_multi_pairing_batch_dev",
@@ -74,6 +74,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_last_hip_error.argtypes = [vp]
     lib.bls381_last_kernel_ms.argtypes = [vp]
     lib.bls381_last_kernel_ms.restype = ctypes.c_float
+    lib.bls381_last_phase_ms.argtypes = [vp, ctypes.c_int]
+    lib.bls381_last_phase_ms.restype = ctypes.c_float
     for name in ("bls381_miller_ref_opt_batch", "bls381_miller_ate_batch", "bls381_pairing_batch"):
         getattr(lib, name).argtypes = [vp, u64p, u64p, u64p, u8p, sz]
     for name in ("bls381_multi_miller_batch", "bls381_multi_pairing_batch"):
@@ -231,6 +233,10 @@ class Engine:
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.bls381_last_kernel_ms(self._ctx))
+
+    def last_phase_ms(self, phase: int) -> float:
+        """Device time of the Miller loops (phase 0) / the final exponentiation (phase 1) of the most recent pairing call."""
+        return float(self.lib.bls381_last_phase_ms(self._ctx, phase))
 
     # host-buffer batch calls ------------------------------------------------
     def optimized_miller_loop(self, g1_jac, g2_jac):
