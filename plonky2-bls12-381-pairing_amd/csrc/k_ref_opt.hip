@@ -1,6 +1,7 @@
 // Kernel translation unit of libbls381_hip.so (see bls381_hip.hip for the C ABI).  The library is split into
 // several TUs only to compile them in parallel; each exposes plain host launch functions (launch.h).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "../../include/bls381_hip.h"
 #include "pairing.hip.h"
 #include "launch.h"
@@ -26,6 +27,8 @@ k_miller_ref_opt(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g
 
 namespace bls_launch {
 void ref_opt(bool fp2_shortcut, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s) {
+  static const bool narrow = getenv("BLS381_NARROW_REF_OPT") != nullptr;      // A/B switch
+  if (!fp2_shortcut && !narrow) { ref_opt_wide(g1, g2, out, flags, n, form, block, s); return; }
   if (fp2_shortcut) hipLaunchKernelGGL(k_miller_ref_opt<false>, dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
   else hipLaunchKernelGGL(k_miller_ref_opt<true>, dim3(grid_for(n, block)), dim3(block), 0, s, g1, g2, out, flags, n, form);
 }

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 namespace bls_launch {
+// Mode A with generic Fq12 accumulators, one wave per SIMD, products inlined (k_ref_opt_wide.hip)
+void ref_opt_wide(const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void ref_opt(bool fp2_shortcut, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 // k in 1..4 pairs per launch, read from arrays that hold `stride` >= k pairs per element (g1 / g2 point at the first pair of
 // element 0 to use); returns false for an unsupported k.  flags_or: OR into flags[] instead of overwriting it.
