@@ -138,22 +138,27 @@ def test_staged_fexp_pipelines(engine, coracle, pipes):
 
 
 def test_staged_fexp_fused_stage_launches(coracle, tmp_path):
-    """The A/B launch forms of the staged final exponentiation -- stages 1..5 as fused two-wave kernels
-    (BLS381_FEXP_FUSED_STAGES) and the two-wave stage 6 (BLS381_NARROW_STAGE6), read from the environment when the library
-    first launches a staged final exponentiation -- in a fresh process, against the oracle."""
+    """The A/B launch forms -- stages 1..5 of the staged final exponentiation as fused two-wave kernels (BLS381_FEXP_FUSED_STAGES),
+    the two-wave stage 6 (BLS381_NARROW_STAGE6), the two-wave generic Mode-A kernel (BLS381_NARROW_REF_OPT); read from the
+    environment at the first such launch of a process -- in a fresh process, against the oracle."""
     import subprocess, sys
     n = (1 << 14) + 77
     g1, g2 = synthetic_batch(n, seed=4242, jacobian=False, pool=64)
     exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
-    np.save(tmp_path / "g1.npy", g1); np.save(tmp_path / "g2.npy", g2)
+    j1, j2 = synthetic_batch(301, seed=4243, jacobian=True, pool=43)
+    expa, efla = coracle.miller_ref_opt(j1, j2, threads=16)
+    for name, arr in (("g1", g1), ("g2", g2), ("j1", j1), ("j2", j2)):
+        np.save(tmp_path / (name + ".npy"), arr)
+    t = lambda name: str(tmp_path / (name + ".npy"))
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import bls381_amd as B; e = B.Engine(0); "
             "e.set_option(B.OPT_FEXP_MODE, B.FEXP_STAGED); "
-            "o, f = e.multi_pairing(np.load(%r), np.load(%r), 1); np.save(%r, o); np.save(%r, f)"
-            % (os.path.dirname(os.path.dirname(B.__file__)), str(tmp_path / "g1.npy"), str(tmp_path / "g2.npy"),
-               str(tmp_path / "out.npy"), str(tmp_path / "fl.npy")))
-    env = dict(os.environ, BLS381_FEXP_FUSED_STAGES="1", BLS381_NARROW_STAGE6="1")
+            "o, f = e.multi_pairing(np.load(%r), np.load(%r), 1); np.save(%r, o); np.save(%r, f); "
+            "o, f = e.optimized_miller_loop(np.load(%r), np.load(%r)); np.save(%r, o); np.save(%r, f)"
+            % (os.path.dirname(os.path.dirname(B.__file__)), t("g1"), t("g2"), t("out"), t("fl"), t("j1"), t("j2"), t("outa"), t("fla")))
+    env = dict(os.environ, BLS381_FEXP_FUSED_STAGES="1", BLS381_NARROW_STAGE6="1", BLS381_NARROW_REF_OPT="1")
     subprocess.check_call([sys.executable, "-c", code], env=env)
-    assert np.array_equal(np.load(tmp_path / "out.npy"), exp) and np.array_equal(np.load(tmp_path / "fl.npy"), efl)
+    assert np.array_equal(np.load(t("out")), exp) and np.array_equal(np.load(t("fl")), efl)
+    assert np.array_equal(np.load(t("outa")), expa) and np.array_equal(np.load(t("fla")), efla)
 
 
 def test_homogeneous_miller_option_domain(engine, coracle):
