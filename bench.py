@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--fexp-pipelines", type=int, default=0, help="BLS381_OPT_FEXP_PIPELINES (1..4; 0 = library default)")
     ap.add_argument("--fexp-mode", type=int, choices=[-1, 0, 1, 2, 3], default=-1,
                     help="BLS381_OPT_FEXP_MODE: 0 self-contained kernel, 1 batched inversion, 2 staged (compressed squarings), "
-                         "3 auto (staged from 2^17 elements); -1 = library default (auto)")
+                         "3 auto (staged from 2^10 elements); -1 = library default (auto)")
     ap.add_argument("--gather", action="store_true", help="after the timed region, collect every rank's results on rank 0 with "
                     "bls381_amd.sharding.gather_outputs (RCCL all_gather over xGMI) and report its time; never part of `value`")
     ap.add_argument("--exchange", type=int, choices=[0, 1], default=-1, help="after the timed region, run the one-rank-owns-the-batch "
@@ -145,7 +145,7 @@ def main(argv=None):
     k = 3 if g16 else 1
     n_units = n // 4 if g16 else n          # 2^18 proofs x 3 pairs (BASELINE config 4)
     if fexp_mode == B.FEXP_AUTO:
-        fexp_mode = B.FEXP_STAGED if n_units >= (1 << 17) else B.FEXP_BATCHED_INVERSION
+        fexp_mode = B.FEXP_STAGED if n_units >= (1 << 10) else B.FEXP_BATCHED_INVERSION
     fexp_kernels = ("k_final_exp", "k_fexp_norm + k_fp_batch_inv + k_final_exp_given",
                     "k_fexp_norm_park + 5 x (k_fp_batch_inv + k_fexp_glue*_wide + k_fexp_chain) + k_fp_batch_inv + k_fexp_stage6_wide, two half-batch pipelines")[fexp_mode]
 

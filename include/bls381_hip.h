@@ -62,7 +62,8 @@ enum {
 
 enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
        BLS381_OPT_FEXP_MODE = 3 /* how the final exponentiation (src/fields_as_trees/miller_loop.rs:128-178) is run; same output bits */,
-       BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams (default 2) */,
+       BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams; 0 (default) = automatic: 2 from 2^18
+          elements, 1 below; an explicit setting applies from 2^14 elements */,
        BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch walks its Miller loop with homogeneous-
           projective curve steps (3 M + 6 S per doubling instead of Alg. 26's 3 M + 8 S, src/miller_loop_native.rs:27-55); the Miller
           value differs by an Fp2 factor that the final exponentiation kills, the pairing is bit-identical FOR POINTS ON THE CURVES
@@ -77,8 +78,8 @@ enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per 
                                              inverted batch-wide: six stage kernels with an inversion kernel before each,
                                              ~6.7 KB of context-owned device scratch per element (batches above 2^20 elements
                                              run in passes of 2^20) */
-       BLS381_FEXP_AUTO = 3,            /* STAGED for batches of at least 2^17 elements (final exponentiation alone: 21.2 vs 21.8 ms at
-                                             2^17, 36.7 vs 42.0 at 2^18, 132.9 vs 162.1 at 2^20; 13.5 vs 11.9 at 2^16), BATCHED_INVERSION
+       BLS381_FEXP_AUTO = 3,            /* STAGED for batches of at least 2^10 elements (final exponentiation alone: 4.8 vs 5.4 ms at 2^10,
+                                             5.4 vs 6.4 at 2^15, 17.8 vs 21.8 at 2^17, 130 vs 162 at 2^20), BATCHED_INVERSION
                                              below, and for a call whose stage
                                              scratch cannot be allocated */
        BLS381_FEXP_DEFAULT = BLS381_FEXP_AUTO };

@@ -5,6 +5,7 @@
 // bls381_create fails with BLS381_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -39,6 +40,7 @@ struct bls381_ctx {
   // tail and stalls of one stage kernel (and the latency-bound inversion kernels) overlap with the other half's work
   static constexpr int MAX_PIPES = 4;
   int pipes = 2;                     // BLS381_OPT_FEXP_PIPELINES
+  bool pipes_set = false;            // ... set by the caller (else: two pipelines from 2^18 elements, one below)
   int hom_miller = 1;                // BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER
   int fexp_chunk_log2 = 20;          // BLS381_OPT_FEXP_CHUNK_LOG2: staged form, elements per pass (bounds the stage scratch)
   hipStream_t aux[MAX_PIPES] = {};
@@ -150,8 +152,8 @@ int bls381_set_option(bls381_ctx* c, int option, int value) {
       if (value < BLS381_FEXP_SELF_CONTAINED || value > BLS381_FEXP_AUTO) return BLS381_E_INVALID;
       c->fexp_mode = value; return BLS381_OK;
     case BLS381_OPT_FEXP_PIPELINES:
-      if (value < 1 || value > bls381_ctx::MAX_PIPES) return BLS381_E_INVALID;
-      c->pipes = value; return BLS381_OK;
+      if (value < 0 || value > bls381_ctx::MAX_PIPES) return BLS381_E_INVALID;
+      c->pipes = value ? value : 2; c->pipes_set = value != 0; return BLS381_OK;      // 0 = automatic
     case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: c->hom_miller = value ? 1 : 0; return BLS381_OK;
     case BLS381_OPT_FEXP_CHUNK_LOG2:
       if (value < 10 || value > 22) return BLS381_E_INVALID;
@@ -167,7 +169,7 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_REF_OPT_FP2_SHORTCUT: *value = c->fp2_shortcut; return BLS381_OK;
     case BLS381_OPT_BLOCK_SIZE: *value = c->block; return BLS381_OK;
     case BLS381_OPT_FEXP_MODE: *value = c->fexp_mode; return BLS381_OK;
-    case BLS381_OPT_FEXP_PIPELINES: *value = c->pipes; return BLS381_OK;
+    case BLS381_OPT_FEXP_PIPELINES: *value = c->pipes_set ? c->pipes : 0; return BLS381_OK;
     case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: *value = c->hom_miller; return BLS381_OK;
     case BLS381_OPT_FEXP_CHUNK_LOG2: *value = c->fexp_chunk_log2; return BLS381_OK;
     default: return BLS381_E_INVALID;
@@ -226,11 +228,19 @@ struct Timed {
 // asynchronous, so a previous call may still be using the buffers: on the same stream the order is implicit; after
 // bls381_set_stream the new stream first waits for the event recorded behind the last user; an outgrown buffer is released
 // only after that user has finished.
-constexpr size_t FEXP_AUTO_STAGED_MIN = (size_t)1 << 17; // BLS381_FEXP_AUTO: staged form from this batch size on (tools/time_fexp_modes.py:
-                                                         // 2^16: 13.5 vs 11.9 ms, 2^17: 21.2 vs 21.8, 2^18: 36.7 vs 42.0, 2^20: 132.9 vs 162.1)
-constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14; // staged form: from this many elements on, two half-batch pipelines
+constexpr size_t FEXP_AUTO_STAGED_MIN = (size_t)1 << 10; // BLS381_FEXP_AUTO: staged form from this batch size on.  With the binary-GCD
+                                                         // inversion it wins at every measured size (tools/time_fexp_modes.py, ms:
+                                                         // 2^10 4.8 vs 5.4, 2^13 5.0 vs 5.5, 2^15 5.4 vs 6.4, 2^17 17.8 vs 21.8, 2^20 130 vs 162)
+constexpr size_t FEXP_PIPELINE_MIN = (size_t)1 << 14;     // smallest batch an explicit BLS381_OPT_FEXP_PIPELINES setting is applied to
+constexpr size_t FEXP_PIPELINE_AUTO_MIN = (size_t)1 << 18; // default: two half-batch pipelines from here on, one below
+                                                         // (tools/time_fexp_pipelines.py: 2^15 5.4 vs 7.1 ms, 2^17 17.8 vs 17.9, 2^18 33.9 vs 33.4)
+// pipelines for a staged final exponentiation of n elements
+int fexp_pipes(const bls381_ctx* c, size_t n) {
+  if (c->pipes_set) return n >= FEXP_PIPELINE_MIN ? c->pipes : 1;
+  return n >= FEXP_PIPELINE_AUTO_MIN ? 2 : 1;
+}
 
-struct FexpPlan { uint32_t* raw = nullptr; uint32_t* stage = nullptr; size_t chunk = 0; };
+struct FexpPlan { uint32_t* raw = nullptr; uint32_t* stage = nullptr; size_t chunk = 0; int pipes = 1; };
 // elements per pipeline and pass: an even share of the chunk, rounded up to a multiple of 128
 size_t fexp_part(size_t chunk, int pipes) { return ((chunk + pipes - 1) / pipes + 127) / 128 * 128; }
 
@@ -243,8 +253,9 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   const size_t max_chunk = (size_t)1 << c->fexp_chunk_log2;   // 2^20 by default: bounds the stage scratch at ~7.0 GB
   const size_t chunk = (staged && n > max_chunk) ? max_chunk : n;
   // staged: every pipeline owns a share of fexp_part(chunk) elements of both scratches
-  const size_t stage_bytes = staged ? (size_t)c->pipes * bls_launch::fexp_stage_scratch_bytes(fexp_part(chunk, c->pipes)) : 0;
-  const size_t raw_elems = staged ? (n > (size_t)c->pipes * fexp_part(chunk, c->pipes) ? n : (size_t)c->pipes * fexp_part(chunk, c->pipes)) : n;
+  const int pipes = fexp_pipes(c, n);
+  const size_t stage_bytes = staged ? (size_t)pipes * bls_launch::fexp_stage_scratch_bytes(fexp_part(chunk, pipes)) : 0;
+  const size_t raw_elems = staged ? (n > (size_t)pipes * fexp_part(chunk, pipes) ? n : (size_t)pipes * fexp_part(chunk, pipes)) : n;
   if (c->raw_scratch_elems < raw_elems || c->stage_scratch_bytes < stage_bytes) {
     if (c->scratch_used) HIP_TRY(c, hipEventSynchronize(c->scratch_done));
     if (c->raw_scratch_elems < raw_elems) {
@@ -268,16 +279,17 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   plan->raw = c->raw_scratch;
   plan->stage = staged ? c->stage_scratch : nullptr;
   plan->chunk = chunk;
+  plan->pipes = pipes;
   return BLS381_OK;
 }
 // the final exponentiation of `n` elements in the context's mode, queued on c->stream (in place allowed)
 int fexp_launch(bls381_ctx* c, const FexpPlan& plan, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
-  if (plan.stage && n >= FEXP_PIPELINE_MIN && c->pipes > 1) {
+  if (plan.stage && plan.pipes > 1) {
     // `pipes` part-batch pipelines: fork from the caller's stream, each part on its own stream and its own share of the
     // scratch, join back.  Parts are cut at multiples of 128 elements so that every launch shape fits its scratch share.
     // Pipeline p starts when pipeline p-1 has its stage 1 through: from then on they are a beat apart, and each one's
     // inversion kernels, ramps and tails fall into the others' stage kernels.
-    const int P = c->pipes;
+    const int P = plan.pipes;
     const size_t part_chunk = fexp_part(plan.chunk, P);           // elements per pipeline and pass (scratch share)
     const size_t part = fexp_part(n, P);                          // elements per pipeline overall
     const size_t stage_dwords_part = bls_launch::fexp_stage_scratch_bytes(part_chunk) / sizeof(uint32_t);
@@ -426,9 +438,11 @@ int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* i
 
 // The pairing-sized entry points: the batch moves in pieces of STAGE_PIECE elements through two device slots, copies on their own
 // streams, so that the upload of piece i+1 and the download of piece i-1 run under the kernels of piece i.  What stays exposed is
-// the first upload and the last download.  A piece is large enough for the staged final exponentiation (2^19 elements).
+// the first upload and the last download.  A piece (2^18 elements) is large enough for the staged final exponentiation to run
+// within 3 % of its full-batch rate and small enough that the exposed copies are 75 MB up and 151 MB down.
 // w1 / w2 / wo: bytes per element of the two inputs and of the output; body(in1, in2, out, flags, first, m) queues m elements on c->stream.
-constexpr size_t STAGE_PIECE = (size_t)1 << 19;
+// 2^18: bench.py --from-host at 2^20 pairings 262.5 ms against 265.1 (2^19) and 270.8 (2^17); 254 ms resident
+static const size_t STAGE_PIECE = (size_t)1 << (getenv("BLS381_STAGE_PIECE_LOG2") ? atoi(getenv("BLS381_STAGE_PIECE_LOG2")) : 18);   // A/B switch
 template <class Body>
 int staged_pipeline(bls381_ctx* c, const void* in1, size_t w1, const void* in2, size_t w2, void* out, size_t wo, uint8_t* flags, size_t n, Body body) {
   HIP_TRY(c, hipSetDevice(c->device));

@@ -247,6 +247,17 @@ def hx(lst):
 from coracle import COracle  # noqa: E402,F401  (oracle/coracle.py: the C restatement, checker only)
 
 
+def inversion_cases():
+    """Values that steer the binary-GCD inversion (csrc/fp.hip.h fp_inv) through its corners: zero, one, p - 1, powers of two
+    and their neighbours (long runs of halvings, approximation windows of every length), multiples near p, any 384-bit pattern."""
+    import random
+    rng = random.Random(2020972)
+    vals = [0, 1, 2, 3, O.P - 1, O.P - 2, (O.P + 1) // 2, (O.P - 1) // 2, O.P, O.P + 1, 2 * O.P - 1, 2 ** 384 - 1, 2 ** 383, 2 ** 381]
+    vals += [1 << k for k in range(1, 384, 7)] + [(1 << k) - 1 for k in range(2, 384, 5)] + [O.P - (1 << k) for k in range(1, 380, 11)]
+    vals += [rng.randrange(1 << rng.randrange(1, 384)) for _ in range(300)] + [rng.randrange(O.P) for _ in range(300)]
+    return vals
+
+
 def synthetic_batch(n, seed=O.SEED, jacobian=False, k=1, pool=64):
     """Small seeded batch in ABI layout for the oracle-sized tests: `pool` (x k) DISTINCT seeded pairs (multiples of the
     generators; Jacobian inputs with random representatives) tiled to n elements -- element i equals element i mod pool.

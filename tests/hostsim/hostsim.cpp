@@ -76,6 +76,7 @@ int hostsim_fp_op(int op, int form, const uint64_t* a, const uint64_t* b, uint64
       case OP_MUL: fp_store(out + 6 * i, mul(x, y), form); break;
       case OP_SQR: fp_store(out + 6 * i, sqr(x), form); break;
       case OP_INV: fp_store(out + 6 * i, fp_inv(x), form); break;
+      case 12: fp_store(out + 6 * i, fp_inv_fermat(x), form); break;      // a^(p-2): cross-check of the binary-GCD inversion
       case OP_NEG: fp_store(out + 6 * i, neg(x), form); break;
       case 8: fp_store(out + 6 * i, mul(x, fp_inv(y)), form); break;
       case 9: fp_store(out + 6 * i, fp_pow_const(x, BLS_P_MINUS_1_DIV_2), form); break;

@@ -37,6 +37,23 @@ def test_fp_ops_and_kat3_montgomery_conversion(engine):
     assert np.array_equal(engine.fp_op(B.FP_FROM_MONT, mont.reshape(-1)), enc_fps(gen, IO_CANONICAL))
 
 
+def test_fp_inverse_corner_cases_on_device(engine):
+    """bls381_fp_op_batch(INV) -- the binary-GCD inversion of csrc/fp.hip.h -- on zero, one, p - 1, powers of two and their
+    neighbours, values near p and arbitrary 384-bit patterns (canonical I/O), against pow(x, p - 2, p); division shares it."""
+    from blsutil import inversion_cases
+    vals = inversion_cases()
+    a = np.array([(v >> (64 * i)) & (2 ** 64 - 1) for v in vals for i in range(6)], dtype=np.uint64)
+    engine.set_option(B.OPT_IO_FORM, IO_CANONICAL)
+    try:
+        got = dec_fps(engine.fp_op(B.FP_INV, a), IO_CANONICAL)
+        one = enc_fps([1] * len(vals), IO_CANONICAL)
+        div = dec_fps(engine.fp_op(B.FP_DIV, one, a), IO_CANONICAL)
+    finally:
+        engine.set_option(B.OPT_IO_FORM, IO_ARK_MONT)
+    exp = [pow(v % O.P, O.P - 2, O.P) for v in vals]
+    assert got == exp and div == exp
+
+
 def test_kat1_kat2_on_device(engine):
     K = load_golden("reference_kats.json")
     engine.set_option(B.OPT_IO_FORM, IO_CANONICAL)     # the reference feeds raw limbs to a canonical-limb type
@@ -406,8 +423,9 @@ def test_full_size_batch_properties(engine, coracle, pools):
 
 def test_staged_fexp_multi_pass_small_chunks(engine, coracle):
     """The `first > 0` passes of the staged final exponentiation (batches above the chunk size) with the chunk lowered to
-    2^12: n = 2 chunks + 77 at one and at two pipelines, every element against the oracle."""
-    n = 2 * 4096 + 77
+    2^12: n = 5 chunks + 77 (above 2^14, where an explicit pipeline count applies) at one, two and three pipelines, every element
+    against the oracle."""
+    n = 5 * 4096 + 77
     g1, g2 = synthetic_batch(n, seed=4242, jacobian=False, pool=64)
     exp, efl = coracle.multi(g1, g2, 1, final_exp=True, threads=16)
     try:
@@ -418,7 +436,7 @@ def test_staged_fexp_multi_pass_small_chunks(engine, coracle):
             out, fl = engine.multi_pairing(g1, g2, 1)
             assert np.array_equal(out, exp) and np.array_equal(fl, efl), pipes
     finally:
-        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_AUTO); engine.set_option(B.OPT_FEXP_CHUNK_LOG2, 20); engine.set_option(B.OPT_FEXP_PIPELINES, 2)
+        engine.set_option(B.OPT_FEXP_MODE, B.FEXP_AUTO); engine.set_option(B.OPT_FEXP_CHUNK_LOG2, 20); engine.set_option(B.OPT_FEXP_PIPELINES, 0)
 
 
 def test_staged_fexp_above_one_chunk_full_size(engine, coracle, pools):
@@ -437,9 +455,10 @@ def test_staged_fexp_above_one_chunk_full_size(engine, coracle, pools):
     assert _oracle_sample(coracle, g1, g2, out, n, 1024)
 
 
-@pytest.mark.parametrize("n", [(1 << 17) - 64, 1 << 17])
+@pytest.mark.parametrize("n", [(1 << 10) - 64, 1 << 10, (1 << 18) - 64, 1 << 18])
 def test_fexp_auto_both_sides_of_the_switch(engine, coracle, pools, n):
-    """BLS381_FEXP_AUTO picks the batched-inversion form below 2^17 elements and the staged form from 2^17 on."""
+    """BLS381_FEXP_AUTO picks the batched-inversion form below 2^10 elements and the staged form from 2^10 on, one pipeline below
+    2^18 elements and two from there on."""
     from bls381_amd import synthetic
     g1, g2 = synthetic.mirrored_affine_batch(pools, n, first=777)
     out, fl = engine.multi_pairing(g1, g2, 1)
@@ -483,9 +502,9 @@ def test_mode_a_64k_batch_properties(engine, coracle):
 
 
 def test_host_pointer_pipeline_pieces_and_slot_reuse(engine, coracle, pools):
-    """The host-pointer entry points move batches above 1.5 * 2^19 elements in pieces of 2^19 through two device slots
-    (upload of piece i+1 and download of piece i-1 under the kernels of piece i): n = 2^20 + 77 is three pieces, so both slots
-    are reused.  Every element against the resident `_dev` path, a sample against the oracle; a reused output buffer."""
+    """The host-pointer entry points move batches above 1.5 * 2^18 elements in pieces of 2^18 through two device slots
+    (upload of piece i+1 and download of piece i-1 under the kernels of piece i): n = 2^20 + 77 is five pieces, so both slots
+    are reused twice.  Every element against the resident `_dev` path, a sample against the oracle; a reused output buffer."""
     import torch
     from bls381_amd import synthetic
     n = (1 << 20) + 77

@@ -4,7 +4,7 @@ This is how kernel logic is validated in the GPU-less container; the GPU parity 
 import random
 
 import numpy as np
-from blsutil import (O, enc_fps, dec_fps, enc_fp12s, dec_fp12s, load_golden, hx, rand_fp, rand_fp2, rand_fp12,
+from blsutil import (O, enc_fps, dec_fps, enc_fp12s, dec_fp12s, load_golden, hx, rand_fp, rand_fp2, rand_fp12, inversion_cases,
                      random_pairs, flat_g1_jac, flat_g2_jac, IO_ARK_MONT, IO_CANONICAL)
 
 
@@ -38,6 +38,14 @@ def test_unreduced_inputs_are_reduced(hostsim):
     one = enc_fps([1] * len(vals), IO_CANONICAL)
     out = dec_fps(hostsim.fp_op(2, a, one, IO_CANONICAL), IO_CANONICAL)
     assert out == [v % O.P for v in vals]
+
+
+def test_fp_inverse_binary_gcd_against_fermat_and_pow(hostsim):
+    vals = inversion_cases()
+    a = np.array([(v >> (64 * i)) & (2 ** 64 - 1) for v in vals for i in range(6)], dtype=np.uint64)
+    got = dec_fps(hostsim.fp_op(4, a, None, IO_CANONICAL), IO_CANONICAL)
+    assert got == [pow(v % O.P, O.P - 2, O.P) for v in vals]
+    assert dec_fps(hostsim.fp_op(12, a, None, IO_CANONICAL), IO_CANONICAL) == got      # a^(p-2) by square-and-multiply
 
 
 def test_fp2_ops(hostsim):
