@@ -287,7 +287,7 @@ def main(argv=None):
         best = min(hs)
         from_host = {"ms_per_step": best * 1e3, "pairings_per_s": n_units / best, "vs_resident": (elapsed / args.steps) / best,
                      "note": "bls381_multi_pairing_batch with pageable numpy buffers the caller re-uses: uploads, kernels and downloads "
-                             "included, pieces of 2^19 elements double-buffered on the context's copy streams"}
+                             "included, pieces of 2^18 elements double-buffered on the context's copy streams"}
 
     # HBM traffic per launch from the last committed PMC passes (tools/collect_profile.sh + summarize_profile.py):
     # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, read side x2 (gfx950).
