@@ -442,7 +442,12 @@ int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* i
 // within 3 % of its full-batch rate and small enough that the exposed copies are 75 MB up and 151 MB down.
 // w1 / w2 / wo: bytes per element of the two inputs and of the output; body(in1, in2, out, flags, first, m) queues m elements on c->stream.
 // 2^18: bench.py --from-host at 2^20 pairings 262.5 ms against 265.1 (2^19) and 270.8 (2^17); 254 ms resident
-static const size_t STAGE_PIECE = (size_t)1 << (getenv("BLS381_STAGE_PIECE_LOG2") ? atoi(getenv("BLS381_STAGE_PIECE_LOG2")) : 18);   // A/B switch
+static int stage_piece_log2() {
+  const char* e = getenv("BLS381_STAGE_PIECE_LOG2");                 // A/B switch, clamped to 2^14 .. 2^22
+  const int v = e ? atoi(e) : 18;
+  return v < 14 ? 14 : (v > 22 ? 22 : v);
+}
+static const size_t STAGE_PIECE = (size_t)1 << stage_piece_log2();
 template <class Body>
 int staged_pipeline(bls381_ctx* c, const void* in1, size_t w1, const void* in2, size_t w2, void* out, size_t wo, uint8_t* flags, size_t n, Body body) {
   HIP_TRY(c, hipSetDevice(c->device));
