@@ -64,7 +64,8 @@ enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_B
        BLS381_OPT_FEXP_MODE = 3 /* how the final exponentiation (src/fields_as_trees/miller_loop.rs:128-178) is run; same output bits */,
        BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams; 0 (default) = automatic: 2 from 2^18
           elements, 1 below; an explicit setting applies from 2^14 elements */,
-       BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch walks its Miller loop with homogeneous-
+       BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER = 5 /* 1 (default): bls381_multi_pairing_batch (and the per-element pair of the prepared /
+          Groth16-shaped products) walks its Miller loop with homogeneous-
           projective curve steps (3 M + 6 S per doubling instead of Alg. 26's 3 M + 8 S, src/miller_loop_native.rs:27-55); the Miller
           value differs by an Fp2 factor that the final exponentiation kills, the pairing is bit-identical FOR POINTS ON THE CURVES
           (what arkworks' affine types hold); for other coordinate values only 0 reproduces the reference's arithmetic.

@@ -623,7 +623,7 @@ int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, con
   int rc;
   {
     Timed t(c);
-    if (!bls_launch::prepared((int)n_var, (int)n_fixed, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
+    if (!bls_launch::prepared((int)n_var, (int)n_fixed, c->hom_miller != 0, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
       return BLS381_E_INVALID;
     c->timed_mid = hipEventRecord(c->ev_mid, c->stream) == hipSuccess;
     rc = fexp_launch(c, plan, out_gt, out_gt, nullptr, n);

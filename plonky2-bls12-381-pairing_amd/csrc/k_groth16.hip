@@ -28,7 +28,10 @@ BLS_HD FpR lds_fp(const uint32_t* p) {
 // NVAR in {0, 1} pairs with a per-element G2 point (full doubling/addition steps), NFIXED in {1, 2} pairs whose G2
 // point is fixed for the batch (prepared coefficients in LDS).  Per element the G1 points come first for the
 // variable pair, then for the fixed pairs.  <1, 2> is the Groth16 shape; <0, 1> is "many P against one Q".
-template <int NVAR, int NFIXED>
+// HOM: the variable pair walks its curve steps in homogeneous projective coordinates (pairing.hip.h); its lines then differ from
+// Alg. 26/27's by Fp2 factors, which the final exponentiation that always follows this kernel kills (same rule and same option,
+// BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER, as for bls381_multi_pairing_batch).  The fixed pairs' lines are the prepared ones either way.
+template <int NVAR, int NFIXED, bool HOM>
 __global__ void __launch_bounds__(G16_BLOCK)
 k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2_var, const uint64_t* __restrict__ prepared,
                   uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
@@ -85,7 +88,8 @@ k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ 
     const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
     for (int pass = 0; pass < passes; ++pass) {
       if constexpr (NVAR == 1) {
-        const LineCoeffs l0 = (pass == 0) ? doubling_step(r) : addition_step(r, q0);
+        const LineCoeffs l0 = HOM ? ((pass == 0) ? doubling_step_hom(r) : addition_step_hom(r, q0))
+                                  : ((pass == 0) ? doubling_step(r) : addition_step(r, q0));
         if (!skip[0]) f = ell(f, l0, p[0]);
       }
 #pragma unroll
@@ -102,13 +106,15 @@ k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ 
 }
 
 namespace bls_launch {
-bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags,
+bool prepared(int nvar, int nfixed, bool hom, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags,
               size_t n, int form, int block, hipStream_t s) {
   const dim3 grid((unsigned)((n * bls::LANES_PER_ELEM + G16_BLOCK - 1) / G16_BLOCK)), blk(G16_BLOCK);
-  if (nvar == 1 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<1, 2>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
-  else if (nvar == 0 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<0, 1>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
-  else if (nvar == 1 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<1, 1>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
-  else if (nvar == 0 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<0, 2>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  if (nvar == 1 && nfixed == 2 && hom) hipLaunchKernelGGL((k_prepared_miller<1, 2, true>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 1 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<1, 2, false>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 0 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<0, 1, false>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 1 && nfixed == 1 && hom) hipLaunchKernelGGL((k_prepared_miller<1, 1, true>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 1 && nfixed == 1) hipLaunchKernelGGL((k_prepared_miller<1, 1, false>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
+  else if (nvar == 0 && nfixed == 2) hipLaunchKernelGGL((k_prepared_miller<0, 2, false>), grid, blk, 0, s, g1, g2_var, prep, out, flags, n, form);
   else return false;
   return true;
 }

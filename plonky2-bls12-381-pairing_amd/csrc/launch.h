@@ -39,8 +39,8 @@ void line_ref_opt(const uint64_t* q1, const uint64_t* q2, const uint64_t* p, uin
 // group 1 = G1 (n x 3 x 6 u64), 2 = G2 (n x 3 x 2 x 6)
 void point_op(int group, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void fill_one(uint64_t* out, size_t n, int form, hipStream_t s);
-// Miller kernel with LDS-staged fixed-G2 coefficients (no final exponentiation)
-bool prepared(int nvar, int nfixed, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
+// Miller kernel with LDS-staged fixed-G2 coefficients (no final exponentiation); hom: homogeneous curve steps for the variable pair
+bool prepared(int nvar, int nfixed, bool hom, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prep, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void fp_pow(const uint64_t* a, const uint64_t* exp, int nwords, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void g2_prepare(const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void witness_inverse(int op, const uint64_t* x, uint64_t* out, uint8_t* flags, size_t n, int block, hipStream_t s);
