@@ -72,6 +72,12 @@ enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_B
           Miller-only entry points always follow Alg. 26/27. */,
        BLS381_OPT_FEXP_CHUNK_LOG2 = 6 /* staged final exponentiation: a batch of more than 2^value elements runs in passes of 2^value
           (10..22, default 20: ~7.0 GB of stage scratch).  Lower it to cap the scratch; the tests lower it to run the multi-pass path. */ };
+/* Read-only through bls381_get_option: what the most recent pairing / final-exponentiation call on this context actually ran
+ * (the automatic choices depend on the batch size and on whether the stage scratch could be allocated); -1 before the first call. */
+enum { BLS381_INFO_LAST_FEXP_MODE = 100       /* BLS381_FEXP_SELF_CONTAINED / _BATCHED_INVERSION / _STAGED; -1: no final exponentiation */,
+       BLS381_INFO_LAST_FEXP_PIPELINES = 101  /* part-batch pipelines of the staged form (1 for the other forms) */,
+       BLS381_INFO_LAST_MILLER_HOMOGENEOUS = 102 /* 1: the Miller loops walked homogeneous-projective curve steps, 0: Alg. 26/27 */,
+       BLS381_INFO_LAST_MILLER_GROUP = 103    /* pairs per Miller launch (k for k <= 4, else 3: groups of three multiplied on device) */ };
 enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per element */
        BLS381_FEXP_BATCHED_INVERSION = 1, /* the Fp inversion under f^-1 (:175) from a batch-wide simultaneous inversion: three launches,
                                              64 B of context-owned device scratch per element */

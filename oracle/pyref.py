@@ -1099,4 +1099,11 @@ if __name__ == "__main__":
     OPS.reset()
     e = final_exponentiation(ml)
     f_ops = OPS.snapshot()
-    print(json.dumps({"modeA_generic": a_ops, "modeB_miller": m_ops, "modeB_finalexp": f_ops}))
+    # the k = 3 product (BASELINE config 4): three pairs through one shared loop, then ONE final exponentiation
+    OPS.reset()
+    g1s = [g1_mul(k) for k in (1, 2, 3)]
+    g2s = [g2_mul(k) for k in (4, 5, 6)]
+    OPS.reset()
+    ml3 = multi_miller_loop(list(zip(g1s, g2s)))
+    m3_ops = OPS.snapshot()
+    print(json.dumps({"modeA_generic": a_ops, "modeB_miller": m_ops, "modeB_finalexp": f_ops, "modeB_miller_k3": m3_ops}))

@@ -43,6 +43,8 @@ struct bls381_ctx {
   bool pipes_set = false;            // ... set by the caller (else: two pipelines from 2^18 elements, one below)
   int hom_miller = 1;                // BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER
   int fexp_chunk_log2 = 20;          // BLS381_OPT_FEXP_CHUNK_LOG2: staged form, elements per pass (bounds the stage scratch)
+  // BLS381_INFO_*: what the most recent call ran (fexp_launch / launch_multi record it)
+  int last_fexp_mode = -1, last_fexp_pipes = -1, last_hom = -1, last_group = -1;
   hipStream_t aux[MAX_PIPES] = {};
   hipEvent_t fork = nullptr, stagger[MAX_PIPES] = {}, join[MAX_PIPES] = {};
   hipStream_t scratch_stream = nullptr;
@@ -172,6 +174,10 @@ int bls381_get_option(const bls381_ctx* c, int option, int* value) {
     case BLS381_OPT_FEXP_PIPELINES: *value = c->pipes_set ? c->pipes : 0; return BLS381_OK;
     case BLS381_OPT_PAIRING_HOMOGENEOUS_MILLER: *value = c->hom_miller; return BLS381_OK;
     case BLS381_OPT_FEXP_CHUNK_LOG2: *value = c->fexp_chunk_log2; return BLS381_OK;
+    case BLS381_INFO_LAST_FEXP_MODE: *value = c->last_fexp_mode; return BLS381_OK;
+    case BLS381_INFO_LAST_FEXP_PIPELINES: *value = c->last_fexp_pipes; return BLS381_OK;
+    case BLS381_INFO_LAST_MILLER_HOMOGENEOUS: *value = c->last_hom; return BLS381_OK;
+    case BLS381_INFO_LAST_MILLER_GROUP: *value = c->last_group; return BLS381_OK;
     default: return BLS381_E_INVALID;
   }
 }
@@ -284,6 +290,8 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
 }
 // the final exponentiation of `n` elements in the context's mode, queued on c->stream (in place allowed)
 int fexp_launch(bls381_ctx* c, const FexpPlan& plan, const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n) {
+  c->last_fexp_mode = plan.stage ? BLS381_FEXP_STAGED : (plan.raw ? BLS381_FEXP_BATCHED_INVERSION : BLS381_FEXP_SELF_CONTAINED);
+  c->last_fexp_pipes = plan.stage ? plan.pipes : 1;
   if (plan.stage && plan.pipes > 1) {
     // `pipes` part-batch pipelines: fork from the caller's stream, each part on its own stream and its own share of the
     // scratch, join back.  Parts are cut at multiples of 128 elements so that every launch shape fits its scratch share.
@@ -299,15 +307,15 @@ int fexp_launch(bls381_ctx* c, const FexpPlan& plan, const uint64_t* in, uint64_
       const size_t cnt = (h == P - 1) ? n - first : (first + part < n ? part : n - first);
       hipEvent_t record_after[6] = {c->stagger[h]};                // behind this pipeline's stage 1
       HIP_TRY(c, hipStreamWaitEvent(c->aux[h], h ? c->stagger[h - 1] : c->fork, 0));
-      if (cnt) bls_launch::final_exp_staged(in + 72 * first, out + 72 * first, flags ? flags + first : nullptr, cnt, c->io_form, c->block,
-                                            c->aux[h], plan.raw + (size_t)h * part_chunk * 16, plan.stage + (size_t)h * stage_dwords_part, part_chunk,
-                                            nullptr, record_after);
+      if (cnt) HIP_TRY(c, bls_launch::final_exp_staged(in + 72 * first, out + 72 * first, flags ? flags + first : nullptr, cnt, c->io_form, c->block,
+                                                       c->aux[h], plan.raw + (size_t)h * part_chunk * 16, plan.stage + (size_t)h * stage_dwords_part, part_chunk,
+                                                       nullptr, record_after));
       else HIP_TRY(c, hipEventRecord(c->stagger[h], c->aux[h]));
       HIP_TRY(c, hipEventRecord(c->join[h], c->aux[h]));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join[h], 0));
     }
   } else if (plan.stage) {
-    bls_launch::final_exp_staged(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw, plan.stage, plan.chunk, nullptr, nullptr);
+    HIP_TRY(c, bls_launch::final_exp_staged(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw, plan.stage, plan.chunk, nullptr, nullptr));
   } else {
     bls_launch::final_exp(in, out, flags, n, c->io_form, c->block, c->stream, plan.raw);
   }
@@ -324,6 +332,7 @@ int launch_ref_opt(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64
   HIP_TRY(c, hipSetDevice(c->device));
   {
     Timed t(c);
+    c->last_hom = -1; c->last_group = -1; c->last_fexp_mode = -1; c->last_fexp_pipes = -1;
     bls_launch::ref_opt(c->fp2_shortcut != 0, g1, g2, out, flags, n, c->io_form, c->block, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
@@ -357,6 +366,9 @@ int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k
   {
     Timed t(c);
     const bool hom = FE && c->hom_miller;
+    c->last_hom = hom ? 1 : 0;
+    c->last_group = (int)(k <= 4 ? k : MULTI_GROUP);
+    if (!FE) { c->last_fexp_mode = -1; c->last_fexp_pipes = -1; }
     if (k <= 4) {
       if (!bls_launch::multi(k, hom, g1, g2, k, out, flags, false, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
     } else {
@@ -419,9 +431,8 @@ int stage_ensure(bls381_ctx* c, int kind, int slot, size_t bytes, void** p) {
 
 // Stages host inputs to the device, runs `body` on device pointers, copies the outputs back (one piece, for the small surfaces).
 template <class Body>
-int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* in2, size_t in2_bytes,
-                 void* out, size_t out_bytes, uint8_t* flags, size_t n, Body body) {
-  HIP_TRY(c, hipSetDevice(c->device));
+int with_staging_queue(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* in2, size_t in2_bytes,
+                       void* out, size_t out_bytes, uint8_t* flags, size_t n, Body& body) {
   void *d1, *d2, *dout, *dfl;
   int rc;
   if ((rc = stage_ensure(c, ST_IN1, 0, in1_bytes, &d1)) || (rc = stage_ensure(c, ST_IN2, 0, in2 ? in2_bytes : 0, &d2)) ||
@@ -432,7 +443,19 @@ int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* i
   if (rc != BLS381_OK) return rc;
   HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
   if (flags) HIP_TRY(c, hipMemcpyAsync(flags, dfl, n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BLS381_OK;
+}
+// Whatever happens while the copies and launches are queued, the call returns only after the stream has drained: queued copies read
+// and write the CALLER's host buffers, which the caller may free or reuse as soon as it sees the return value, and the next call
+// assumes the staging buffers are idle.
+template <class Body>
+int with_staging(bls381_ctx* c, const void* in1, size_t in1_bytes, const void* in2, size_t in2_bytes,
+                 void* out, size_t out_bytes, uint8_t* flags, size_t n, Body body) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int rc = with_staging_queue(c, in1, in1_bytes, in2, in2_bytes, out, out_bytes, flags, n, body);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (rc != BLS381_OK) return rc;
+  HIP_TRY(c, e);
   return BLS381_OK;
 }
 
@@ -449,8 +472,7 @@ static int stage_piece_log2() {
 }
 static const size_t STAGE_PIECE = (size_t)1 << stage_piece_log2();
 template <class Body>
-int staged_pipeline(bls381_ctx* c, const void* in1, size_t w1, const void* in2, size_t w2, void* out, size_t wo, uint8_t* flags, size_t n, Body body) {
-  HIP_TRY(c, hipSetDevice(c->device));
+int staged_pipeline_queue(bls381_ctx* c, const void* in1, size_t w1, const void* in2, size_t w2, void* out, size_t wo, uint8_t* flags, size_t n, Body& body) {
   const size_t piece = (n <= STAGE_PIECE + STAGE_PIECE / 2) ? n : STAGE_PIECE;
   const size_t pieces = (n + piece - 1) / piece;
   const int slots = pieces > 1 ? 2 : 1;
@@ -479,13 +501,21 @@ int staged_pipeline(bls381_ctx* c, const void* in1, size_t w1, const void* in2, 
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_ready[sl], 0));
     if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->out_copied[sl], 0));    // piece i-2 has left the output slot
     const int rc = body((const uint64_t*)d1[sl], (const uint64_t*)d2[sl], (uint64_t*)dout[sl], (uint8_t*)dfl[sl], first, m);
-    if (rc != BLS381_OK) { (void)hipDeviceSynchronize(); return rc; }
+    if (rc != BLS381_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->computed[sl], c->stream));
     if (i >= 1) { const int r2 = download(i - 1); if (r2 != BLS381_OK) return r2; }   // blocks the host at most until piece i-1 is computed; piece i is queued
   }
-  { const int r2 = download(pieces - 1); if (r2 != BLS381_OK) return r2; }
-  HIP_TRY(c, hipStreamSynchronize(c->d2h));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return download(pieces - 1);
+}
+// One exit for every outcome (see with_staging): the three streams are drained before the call returns, also after an error in the
+// middle of the loop -- copies already queued on h2d / d2h / stream touch the caller's buffers and the context's two slots.
+template <class Body>
+int staged_pipeline(bls381_ctx* c, const void* in1, size_t w1, const void* in2, size_t w2, void* out, size_t wo, uint8_t* flags, size_t n, Body body) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int rc = staged_pipeline_queue(c, in1, w1, in2, w2, out, wo, flags, n, body);
+  const hipError_t e0 = hipStreamSynchronize(c->h2d), e1 = hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->d2h);
+  if (rc != BLS381_OK) return rc;
+  HIP_TRY(c, e0); HIP_TRY(c, e1); HIP_TRY(c, e2);
   return BLS381_OK;
 }
 
@@ -623,6 +653,7 @@ int bls381_prepared_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1_aff, con
   int rc;
   {
     Timed t(c);
+    c->last_hom = c->hom_miller ? 1 : 0; c->last_group = (int)(n_var + n_fixed);
     if (!bls_launch::prepared((int)n_var, (int)n_fixed, c->hom_miller != 0, g1_aff, g2_var, prepared_fixed, out_gt, flags, n, c->io_form, c->block, c->stream))
       return BLS381_E_INVALID;
     c->timed_mid = hipEventRecord(c->ev_mid, c->stream) == hipSuccess;
@@ -811,16 +842,22 @@ int bls381_create_multi(bls381_multi** out, const int* device_ids, int n_devices
   *out = nullptr;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BLS381_E_NO_DEVICE;
-  std::vector<int> ids;
-  if (!device_ids || n_devices <= 0) { for (int i = 0; i < count; ++i) ids.push_back(i); }
-  else ids.assign(device_ids, device_ids + n_devices);
-  bls381_multi* m = new (std::nothrow) bls381_multi();
-  if (!m) return BLS381_E_NOMEM;
-  for (int id : ids) {
-    bls381_ctx* c = nullptr;
-    const int rc = bls381_create(&c, id);
-    if (rc != BLS381_OK) { bls381_destroy_multi(m); return rc; }
-    m->ctx.push_back(c);
+  bls381_multi* m = nullptr;
+  try {                                        // std::vector growth may throw: nothing unwinds through the C ABI
+    std::vector<int> ids;
+    if (!device_ids || n_devices <= 0) { for (int i = 0; i < count; ++i) ids.push_back(i); }
+    else ids.assign(device_ids, device_ids + n_devices);
+    m = new bls381_multi();
+    m->ctx.reserve(ids.size());
+    for (int id : ids) {
+      bls381_ctx* c = nullptr;
+      const int rc = bls381_create(&c, id);
+      if (rc != BLS381_OK) { bls381_destroy_multi(m); return rc; }
+      m->ctx.push_back(c);
+    }
+  } catch (...) {
+    bls381_destroy_multi(m);
+    return BLS381_E_NOMEM;
   }
   *out = m;
   return BLS381_OK;
@@ -851,17 +888,31 @@ namespace {
 template <class Run>
 int sharded(bls381_multi* m, size_t n, Run run) {
   const size_t G = m->ctx.size();
-  std::vector<int> rc(G, BLS381_OK);
-  std::vector<std::thread> th;
-  for (size_t g = 0; g < G; ++g) {
-    const size_t lo = n * g / G, hi = n * (g + 1) / G;
-    if (hi == lo) continue;
-    if (G == 1) rc[g] = run(m->ctx[g], lo, hi - lo);
-    else th.emplace_back([&, g, lo, hi] { rc[g] = run(m->ctx[g], lo, hi - lo); });
+  // No exception leaves this function (the callers are extern "C"): allocation failures answer BLS381_E_NOMEM; a range whose
+  // thread cannot be started (std::system_error) runs inline on the calling thread after the started ones are joined.
+  try {
+    std::vector<int> rc(G, BLS381_OK);
+    std::vector<char> pending(G, 0);
+    std::vector<std::thread> th;
+    th.reserve(G);
+    for (size_t g = 0; g < G; ++g) {
+      const size_t lo = n * g / G, hi = n * (g + 1) / G;
+      if (hi == lo) continue;
+      if (G == 1) { rc[g] = run(m->ctx[g], lo, hi - lo); continue; }
+      try {
+        th.emplace_back([&rc, &run, m, g, lo, hi] { rc[g] = run(m->ctx[g], lo, hi - lo); });
+      } catch (...) {
+        pending[g] = 1;
+      }
+    }
+    for (auto& t : th) t.join();
+    for (size_t g = 0; g < G; ++g)
+      if (pending[g]) rc[g] = run(m->ctx[g], n * g / G, n * (g + 1) / G - n * g / G);
+    for (int r : rc) if (r != BLS381_OK) return r;
+    return BLS381_OK;
+  } catch (...) {
+    return BLS381_E_NOMEM;
   }
-  for (auto& t : th) t.join();
-  for (int r : rc) if (r != BLS381_OK) return r;
-  return BLS381_OK;
 }
 }  // namespace
 

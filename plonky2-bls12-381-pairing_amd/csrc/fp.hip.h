@@ -628,8 +628,11 @@ BLS_HD_NOINLINE FpR fp_inv(const Fp<L, V>& a_in) {
       found = found || take;
     }
     const uint32_t top = ha | hb;
-    int s = top ? 32 - __builtin_clz(top) : 0;            // bit length of the window's top limb, at least 2 (n >= 62)
-    s = s < 2 ? 2 : s;
+    int s = top ? 32 - __builtin_clz(top) : 0;            // bit length of the window's top limb
+    // no limb above limb 2 in use: the window is bits [30, 90) and n = max(len, 62), i.e. s >= 2.  Otherwise s as it is: wa >> s then
+    // holds exactly the 32 bits below bit n that Alg. 2 asks for (with the clamp applied everywhere a top limb of bit length 1 kept
+    // only 31 of them -- still convergent with ~17 spare halvings in 26 rounds, but not what the convergence argument covers).
+    s = (!found && s < 2) ? 2 : s;
     // floor(value / 2^(30 t - 32)) >> s = the 32 bits below bit n (t = index of the window's top limb)
     const uint64_t wa = ((((uint64_t)ha << GCD_W) | ma) << 2) | (la >> 28);
     const uint64_t wb = ((((uint64_t)hb << GCD_W) | mb) << 2) | (lb >> 28);
@@ -647,7 +650,7 @@ BLS_HD_NOINLINE FpR fp_inv(const Fp<L, V>& a_in) {
       f0 -= odd ? f1 : 0;
       g0 -= odd ? g1 : 0;
       xa >>= 1;
-      f1 <<= 1; g1 <<= 1;
+      f1 = (int32_t)((uint32_t)f1 << 1); g1 = (int32_t)((uint32_t)g1 << 1);   // doubling of a possibly negative factor: shift as unsigned
     }
     int32_t na[GCD_L], nb[GCD_L];
     gcd_apply<false>(na, f0, g0, a, b);

@@ -20,7 +20,7 @@ static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bl
 //
 // k_final_exp is the self-contained form (one Fermat inversion per lane, ~9 % of the kernel).  The split form amortises
 // that inversion over the batch:  k_fexp_norm writes the Fp norm under f^-1 for every element,  k_fp_batch_inv
-// (k_misc.hip) inverts them eight per lane with Montgomery's trick,  k_final_exp_given finishes f^-1 from the supplied
+// (k_misc.hip) inverts them sixteen per lane with Montgomery's trick,  k_final_exp_given finishes f^-1 from the supplied
 // norm inverse and runs the rest.  Same field values, hence the same output bits.
 __global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form) {
@@ -99,9 +99,10 @@ size_t fexp_stage_scratch_bytes(size_t n_chunk) {      // for a chunk of n_chunk
 }
 // Staged final exponentiation over chunks of at most `chunk` elements; raw_scratch: chunk x RAW_FP_STRIDE dwords,
 // stage_scratch: fexp_stage_scratch_bytes(chunk)
-void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
-                      uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
-                      const hipEvent_t* wait_before, const hipEvent_t* record_after) {
+hipError_t final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
+                            uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
+                            const hipEvent_t* wait_before, const hipEvent_t* record_after) {
+  hipError_t err = hipSuccess;     // a failed wait would turn the pipelines' ordering into a race: reported, not swallowed
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first < chunk) ? n - first : chunk;
     const dim3 grid(grid_for(m, block)), blk(block);
@@ -110,8 +111,9 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
     uint64_t* co = out + 72 * first;
     uint8_t* cf = flags ? flags + first : nullptr;
     // events tie the stage kernels of the first pass to another pipeline's (see bls381_hip.hip)
-    auto before = [&](int k) { if (first == 0 && wait_before && wait_before[k]) (void)hipStreamWaitEvent(s, wait_before[k], 0); };
-    auto after = [&](int k) { if (first == 0 && record_after && record_after[k]) (void)hipEventRecord(record_after[k], s); };
+    auto note = [&](hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; };
+    auto before = [&](int k) { if (first == 0 && wait_before && wait_before[k]) note(hipStreamWaitEvent(s, wait_before[k], 0)); };
+    auto after = [&](int k) { if (first == 0 && record_after && record_after[k]) note(hipEventRecord(record_after[k], s)); };
     hipLaunchKernelGGL(k_fexp_norm_park, grid, blk, 0, s, ci, stage_scratch, raw_scratch, m, lanes, form);
     fp_batch_inv_raw(raw_scratch, m, s);
     // stages 1..5: glue + squaring chain, fused in one two-wave kernel or as a one-wave glue kernel plus the chain kernel
@@ -139,6 +141,7 @@ void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t 
     else fexp_stage6_wide(co, cf, stage_scratch, raw_scratch, m, lanes, form, block, s);
     after(5);
   }
+  return err;
 }
 // `raw_scratch`: n x RAW_FP_STRIDE dwords of device memory for the split form, or nullptr for the self-contained kernel
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch) {

@@ -24,7 +24,8 @@ void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s);
 // raw_scratch: chunk x 16 dwords, stage_scratch: fexp_stage_scratch_bytes(chunk) bytes; wait_before[k] / record_after[k]
 // (arrays of six, entries or the arrays may be null) are waited for before / recorded behind stage kernel k+1 of the first pass
 size_t fexp_stage_scratch_bytes(size_t n_chunk);
-void final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
+// returns the first HIP error of the event waits / records that order the stage kernels against other pipelines (hipSuccess otherwise)
+hipError_t final_exp_staged(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s,
                       uint32_t* raw_scratch, uint32_t* stage_scratch, size_t chunk,
                       const hipEvent_t* wait_before, const hipEvent_t* record_after);
 // stage 6 of the staged form compiled for one wave per SIMD (k_fexp_wide.hip); same arguments as the stage kernels

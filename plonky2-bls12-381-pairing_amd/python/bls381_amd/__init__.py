@@ -20,6 +20,8 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libbls381_hi
 IO_ARK_MONT, IO_CANONICAL = 0, 1
 OPT_IO_FORM, OPT_REF_OPT_FP2_SHORTCUT, OPT_BLOCK_SIZE, OPT_FEXP_MODE, OPT_FEXP_PIPELINES, OPT_PAIRING_HOMOGENEOUS_MILLER = 0, 1, 2, 3, 4, 5
 OPT_FEXP_CHUNK_LOG2 = 6
+# read-only (get_option): what the most recent call ran
+INFO_LAST_FEXP_MODE, INFO_LAST_FEXP_PIPELINES, INFO_LAST_MILLER_HOMOGENEOUS, INFO_LAST_MILLER_GROUP = 100, 101, 102, 103
 FEXP_SELF_CONTAINED, FEXP_BATCHED_INVERSION, FEXP_STAGED, FEXP_AUTO = 0, 1, 2, 3
 FLAG_DEN_ZERO, FLAG_INFINITY = 1, 2
 FLAG_TRUE = 32

@@ -127,6 +127,8 @@ def _ptr(a, ty=ctypes.c_uint64):
 
 def build_hostsim():
     """g++ build of the device headers for the host (tests/hostsim); returns the ctypes handle."""
+    if os.environ.get("BLS381_HOSTSIM_SO"):            # an instrumented build (tools/sanitize_host.sh)
+        return ctypes.CDLL(os.environ["BLS381_HOSTSIM_SO"])
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
     so = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
     inc = os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "csrc")
@@ -255,6 +257,8 @@ def inversion_cases():
     vals = [0, 1, 2, 3, O.P - 1, O.P - 2, (O.P + 1) // 2, (O.P - 1) // 2, O.P, O.P + 1, 2 * O.P - 1, 2 ** 384 - 1, 2 ** 383, 2 ** 381]
     vals += [1 << k for k in range(1, 384, 7)] + [(1 << k) - 1 for k in range(2, 384, 5)] + [O.P - (1 << k) for k in range(1, 380, 11)]
     vals += [rng.randrange(1 << rng.randrange(1, 384)) for _ in range(300)] + [rng.randrange(O.P) for _ in range(300)]
+    # bit length 30 t + 1: the top 30-bit limb of the first approximation window is exactly 1 (the un-clamped shift of fp_inv)
+    vals += [(1 << (30 * t)) + r for t in range(3, 13) for r in (0, 1, rng.randrange(1 << (30 * t)))]
     return vals
 
 

@@ -772,6 +772,76 @@ def test_groth16_fixed_g2_path(engine, coracle):
     assert O.fp12_is_one(dec_fp12s(out[7 * 72:8 * 72])[0]) and fl[5] == 2 and fl[6] == 2 and fl[7] == 2
 
 
+def _groth16_shape_batch(pools, n, fixed=None, first=0):
+    """n proofs x 3 pairs from the GPU-built pools (bls381_amd/synthetic.py indices).  The second half of the batch holds the
+    first half's proofs written differently: every per-proof pair mirrored -- ((a+1) G1, (b+1) G2) -> ((b+1) G1, (a+1) G2), the
+    same pairing value from different inputs -- and, in the generic shape, the three pairs rotated (a product does not depend on
+    the order of its factors).  fixed = (f1, f2): pairs 1 and 2 use the pool points Q[f1], Q[f2] on EVERY proof (the verifying
+    key's points of a Groth16 batch); only pair 0 is mirrored then.  Returns g1 [n, 3, 12], g2 [n, 3, 24] (uint64)."""
+    from bls381_amd import synthetic
+    p1, p2 = pools
+    h = n // 2
+    ia, ib = synthetic.element_indices(h * 3, p1.shape[0], first * 3)
+    ia, ib = ia.reshape(h, 3), ib.reshape(h, 3)
+    if fixed is None:
+        rot = [1, 2, 0]
+        g1 = np.concatenate([p1[ia], p1[ib[:, rot]]])
+        g2 = np.concatenate([p2[ib], p2[ia[:, rot]]])
+    else:
+        g1 = np.concatenate([p1[ia], p1[np.stack([ib[:, 0], ia[:, 1], ia[:, 2]], axis=1)]])
+        g2 = np.concatenate([p2[ib], p2[np.stack([ia[:, 0], ib[:, 1], ib[:, 2]], axis=1)]])
+        g2[:, 1] = p2[fixed[0]]
+        g2[:, 2] = p2[fixed[1]]
+    return np.ascontiguousarray(g1), np.ascontiguousarray(g2)
+
+
+def _spread(n, count):
+    """`count` element indices spread over [0, n) with a stride coprime to the pool size, first and last element included"""
+    idx = (np.arange(count, dtype=np.int64) * 4099 + 17) % n
+    idx[0], idx[-1] = 0, n - 1
+    return idx
+
+
+@pytest.mark.parametrize("lg", [15, 18])
+def test_groth16_shape_at_size_generic(engine, coracle, pools, lg):
+    """BASELINE config 4 (3 pairs x 2^18 proofs; 2^15 = one GPU's share of it on 8 GPUs), generic k = 3 product
+    (bls381_multi_pairing_batch: `multi_miller_loop(terms)` of src/miller_loop_native.rs:154-212 + the final exponentiation):
+    (1) proof i + n/2 = proof i with its pairs mirrored and rotated -> the two halves must be equal bit for bit, no two compared
+    elements computed from the same inputs; (2) 768 proofs spread over the batch against the C oracle's k = 3 product."""
+    n = 1 << lg
+    g1, g2 = _groth16_shape_batch(pools, n, first=4242)
+    out, fl = engine.multi_pairing(g1.reshape(-1), g2.reshape(-1), 3)
+    assert not fl.any()
+    o = out.reshape(2, n // 2, 72)
+    assert np.array_equal(o[0], o[1])
+    assert len(np.unique(o[0][:, :6], axis=0)) > (n // 2) * 0.8            # distinct products, not a tiled pool
+    idx = _spread(n, 768)
+    exp, efl = coracle.multi(g1[idx].reshape(-1), g2[idx].reshape(-1), 3, final_exp=True, threads=16)
+    assert np.array_equal(out.reshape(n, 72)[idx].reshape(-1), exp) and not efl.any()
+
+
+@pytest.mark.parametrize("lg", [15, 18])
+def test_groth16_shape_at_size_prepared(engine, coracle, pools, lg):
+    """The same shape with the two fixed G2 points prepared (bls381_groth16_pairing_batch: `G2PreparedTarget` coefficients,
+    src/miller_loop_target.rs:23-76, consumed from LDS): (1) EVERY element equal to the generic k = 3 product of the same
+    inputs (another kernel: k_multi_miller<3> walks three curves, k_prepared_miller<1,2> walks one and reads 2 x 68 coefficient
+    triples); (2) halves equal under mirroring of the per-proof pair; (3) 768 spread proofs against the C oracle."""
+    n = 1 << lg
+    f1, f2 = 17, 4000
+    g1, g2 = _groth16_shape_batch(pools, n, fixed=(f1, f2), first=777)
+    prep, pfl = engine.g2_prepare(np.ascontiguousarray(g2[0, 1:3]).reshape(-1))
+    assert not pfl.any()
+    out, fl = engine.groth16_pairing(g1.reshape(-1), np.ascontiguousarray(g2[:, 0]).reshape(-1), prep)
+    assert not fl.any()
+    gen, gfl = engine.multi_pairing(g1.reshape(-1), g2.reshape(-1), 3)
+    assert np.array_equal(out, gen) and not gfl.any()
+    o = out.reshape(2, n // 2, 72)
+    assert np.array_equal(o[0], o[1])
+    idx = _spread(n, 768)
+    exp, _ = coracle.multi(g1[idx].reshape(-1), g2[idx].reshape(-1), 3, final_exp=True, threads=16)
+    assert np.array_equal(out.reshape(n, 72)[idx].reshape(-1), exp)
+
+
 @pytest.mark.parametrize("n_var,n_fixed", [(0, 1), (1, 1), (0, 2)])
 def test_prepared_pairing_shapes(engine, coracle, n_var, n_fixed):
     """bls381_prepared_pairing_batch: every supported (variable, fixed) shape equals the generic product."""
