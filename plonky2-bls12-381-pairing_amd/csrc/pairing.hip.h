@@ -474,4 +474,139 @@ BLS_HD G2Aff g2_aff_load(const uint64_t* w, int form, bool& inf) {
   G2Aff q; q.x = fp2_load(w, form); q.y = fp2_load(w + 12, form); return q;
 }
 
+#if BLS_LANES == 2
+// ---- the same loop with the per-pair state parked in LDS (device kernels, lane-pair layout).
+// What a lane must keep through an iteration of miller_ate is f (84 registers), and per pair R (42), Q (28) and P (28): with the
+// working set of the Fq12 squaring (~170) one pair just fits 512 registers, two or three do not -- the compiler then keeps r[], q[], p[]
+// in the private segment (1.0-1.4 KB per lane, walked with a run-time pair index) and a lone wave per SIMD waits out every scratch
+// access.  Here the pair index is a run-time loop by design and the state that is not being worked on lives in LDS:
+//   * P: one converted coordinate per lane (even lane x, odd lane y; both lanes read both) -- K slots;
+//   * R of the pairs that are not current: K - 1 slots of three values; the current R stays in registers and CHANGES PLACES with the
+//     slot of the pair that is next (the slots hold the pairs in FIFO order, so slot number = step count mod (K - 1));
+//   * Q: not kept at all -- the five addition steps of the loop re-read it from the input array (one conversion per coordinate).
+// A slot is 16 dwords per lane (14 used), lane-sliced in four 16-byte quarters like LaneScratch: every LDS instruction of a wave
+// moves 64 consecutive 16-byte pieces, no bank conflicts.  K = 3: (2 x 3 + 3) x 64 B = 576 B per lane, 36 KB per wave, four waves per CU.
+struct alignas(16) LdsQuad { uint32_t w[4]; };
+// LANES = lanes of the workgroup, a compile-time constant: slot addresses are then ONE per-lane base register plus immediate offsets
+// (ds_read_b128 / ds_write_b128 offset field) -- with a run-time stride the compiler hoists one address register per (slot, quarter)
+// out of the loop and spills them.
+template <int LANES>
+struct LaneLds {
+  LdsQuad* mine;          // this lane's column:  base + lane
+  LdsQuad* pair0;         // the even lane of this lane's pair:  base + (lane & ~1)
+  BLS_HD void put(int slot, const FpR& a) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      LdsQuad v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v.w[j] = (4 * q + j < NL) ? a.l[4 * q + j] : 0u;
+      mine[(4 * slot + q) * LANES] = v;
+    }
+  }
+  static BLS_HD FpR get_at(const LdsQuad* col, int slot) {
+    FpR r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const LdsQuad v = col[(4 * slot + q) * LANES];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (4 * q + j < NL) r.l[4 * q + j] = v.w[j];
+    }
+    return r;
+  }
+  BLS_HD FpR get(int slot) const { return get_at(mine, slot); }
+  BLS_HD FpR get_even(int slot) const { return get_at(pair0, slot); }      // the value the even lane of the pair put
+  BLS_HD FpR get_odd(int slot) const { return get_at(pair0 + 1, slot); }   // ... the odd lane
+};
+template <int LANES>
+BLS_HD LaneLds<LANES> lane_lds(LdsQuad* base, unsigned lane) { return LaneLds<LANES>{base + lane, base + (lane & ~1u)}; }
+// scheduling fence: keeps the instruction scheduler from hoisting the next phase's loads above the current phase (register pressure)
+BLS_HD void phase_fence() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_LDS_NOFENCE)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// compiler-level memory barrier: the LDS reads behind it are not hoisted out of the loop (P is loop-invariant data; hoisted it
+// would be live -- and spilled -- through the whole loop, which is what parking it in LDS is meant to avoid)
+BLS_HD void lds_reload_point() {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BLS_LDS_MEMBAR)
+  asm volatile("" ::: "memory");
+#endif
+}
+constexpr int miller_lds_slots(int k) { return 3 * (k - 1) + k; }            // per lane, 64 bytes each
+constexpr size_t miller_lds_bytes_per_lane(int k) { return (size_t)miller_lds_slots(k) * 64; }
+
+// g1e / g2e: the element's first pair in the caller's arrays (12 / 24 u64 per pair); returns the Miller value, ORs the flag bits
+template <int K, bool HOM, int LANES>
+BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, const LaneLds<LANES>& lds, uint8_t& fl) {
+  constexpr int P_BASE = 3 * (K - 1);
+  unsigned skip = 0;
+  G2Jac cur;
+#if defined(BLS_LDS_KEEP_P) || defined(BLS_LDS_KEEP_Q)
+  static_assert(K == 1, "experiment switches");
+  G1Aff p_reg; G2Aff q_reg;
+#endif
+  for (int j = 0; j < K; ++j) {
+    bool i1, i2;
+    const G1Aff p = g1_aff_load(g1e + 12 * j, form, i1);
+    const G2Aff q = g2_aff_load(g2e + 24 * j, form, i2);
+#if defined(BLS_LDS_KEEP_P) || defined(BLS_LDS_KEEP_Q)
+    p_reg = p; q_reg = q;
+#endif
+    if (i1 || i2) { skip |= 1u << j; fl |= FLAG_INFINITY; }
+    lds.put(P_BASE + j, lane_part() == 0 ? p.x : p.y);
+    const Fp2R one = Fp2R(fp2_one());
+    if (j == 0) { cur.x = q.x; cur.y = q.y; cur.z = one; }
+    else { lds.put(3 * (j - 1) + 0, q.x.v); lds.put(3 * (j - 1) + 1, q.y.v); lds.put(3 * (j - 1) + 2, one.v); }
+  }
+  Fp12R f = fp12_one();
+  int slot = 0;                                    // the slot that holds the pair after the current one
+  for (int b = 61; b >= -1; --b) {
+    const bool last = b < 0;
+    const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    BLS_MILLER_ITERATION_HOOK();
+    for (int pass = 0; pass < passes; ++pass) {
+#pragma clang loop unroll(disable)
+      for (int j = 0; j < K; ++j) {
+        LineCoeffs l;
+        if (pass == 0) {
+          l = HOM ? doubling_step_hom(cur) : doubling_step(cur);
+        } else {
+#ifdef BLS_LDS_KEEP_Q
+          const G2Aff q = q_reg;
+#else
+          bool inf;
+          const G2Aff q = g2_aff_load(g2e + 24 * j, form, inf);
+#endif
+          l = HOM ? addition_step_hom(cur, q) : addition_step(cur, q);
+        }
+        phase_fence();
+        if (!((skip >> j) & 1u)) {
+          G1Aff p;
+#ifdef BLS_LDS_KEEP_P
+          p = p_reg;
+#else
+          lds_reload_point();
+          p.x = lds.get_even(P_BASE + j);
+          p.y = lds.get_odd(P_BASE + j);
+#endif
+          // the very first line meets f = 1: no multiplication (a uniform branch; a skipped first pair leaves f = 1 for the next)
+          f = (BLS_MILLER_PEEL && b == 61 && pass == 0 && j == 0) ? line_value(l, p) : ell(f, l, p);
+        }
+        phase_fence();
+        if (K > 1) {                                // the current R changes places with the next pair's
+          G2Jac nx;
+          nx.x = Fp2R(lds.get(3 * slot + 0)); nx.y = Fp2R(lds.get(3 * slot + 1)); nx.z = Fp2R(lds.get(3 * slot + 2));
+          lds.put(3 * slot + 0, cur.x.v); lds.put(3 * slot + 1, cur.y.v); lds.put(3 * slot + 2, cur.z.v);
+          cur = nx;
+          slot = (slot + 1 == K - 1) ? 0 : slot + 1;
+          phase_fence();
+        }
+      }
+    }
+    if (!last) f = sqr(f);
+  }
+  return fit<1, 2>(conj(f));
+}
+#endif
+
 }  // namespace bls
