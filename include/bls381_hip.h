@@ -71,7 +71,7 @@ enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_B
           (what arkworks' affine types hold); for other coordinate values only 0 reproduces the reference's arithmetic.
           Miller-only entry points always follow Alg. 26/27. */,
        BLS381_OPT_FEXP_CHUNK_LOG2 = 6 /* staged final exponentiation: a batch of more than 2^value elements runs in passes of 2^value
-          (10..22, default 20: ~7.0 GB of stage scratch).  Lower it to cap the scratch; the tests lower it to run the multi-pass path. */ };
+          (10..22, default 20: ~6.1 GB of stage scratch).  Lower it to cap the scratch; the tests lower it to run the multi-pass path. */ };
 /* Read-only through bls381_get_option: what the most recent pairing / final-exponentiation call on this context actually ran
  * (the automatic choices depend on the batch size and on whether the stage scratch could be allocated); -1 before the first call. */
 enum { BLS381_INFO_LAST_FEXP_MODE = 100       /* BLS381_FEXP_SELF_CONTAINED / _BATCHED_INVERSION / _STAGED; -1: no final exponentiation */,
@@ -83,7 +83,7 @@ enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per 
                                              64 B of context-owned device scratch per element */
        BLS381_FEXP_STAGED = 2,          /* additionally Karabina-compressed cyclotomic squarings, their decompression denominators
                                              inverted batch-wide: six stage kernels with an inversion kernel before each,
-                                             ~6.7 KB of context-owned device scratch per element (batches above 2^20 elements
+                                             ~5.8 KB of context-owned device scratch per element (batches above 2^20 elements
                                              run in passes of 2^20) */
        BLS381_FEXP_AUTO = 3,            /* STAGED for batches of at least 2^10 elements (final exponentiation alone: 4.8 vs 5.4 ms at 2^10,
                                              5.4 vs 6.4 at 2^15, 17.8 vs 21.8 at 2^17, 130 vs 162 at 2^20), BATCHED_INVERSION

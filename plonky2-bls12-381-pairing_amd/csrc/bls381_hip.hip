@@ -256,7 +256,7 @@ int fexp_acquire(bls381_ctx* c, size_t n, FexpPlan* plan) {
   if (c->scratch_used && c->scratch_stream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->scratch_done, 0));
   bool staged = c->fexp_mode == BLS381_FEXP_STAGED || (c->fexp_mode == BLS381_FEXP_AUTO && n >= FEXP_AUTO_STAGED_MIN);
   // raw scratch always covers the whole batch (the batched-inversion form, also the fallback, is not chunked)
-  const size_t max_chunk = (size_t)1 << c->fexp_chunk_log2;   // 2^20 by default: bounds the stage scratch at ~7.0 GB
+  const size_t max_chunk = (size_t)1 << c->fexp_chunk_log2;   // 2^20 by default: bounds the stage scratch at ~6.1 GB
   const size_t chunk = (staged && n > max_chunk) ? max_chunk : n;
   // staged: every pipeline owns a share of fexp_part(chunk) elements of both scratches
   const int pipes = fexp_pipes(c, n);

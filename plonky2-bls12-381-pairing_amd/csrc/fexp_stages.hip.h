@@ -102,7 +102,9 @@ constexpr int FX_COMP_BASE = FX_SLOTS * 6;
 constexpr int FX_PRE_BASE = FX_COMP_BASE + 6 * 4;
 constexpr int FX_X_BASE = FX_PRE_BASE + 6;                                       // input of the next squaring chain (split launch)
 constexpr int FX_FP2_TOTAL = FX_X_BASE + 4;                                      // 52 Fp2 per element
-constexpr int FX_DWORDS_PER_LANE = FX_FP2_TOTAL * SCRATCH_FP_PER_FP2 * 16;       // 16 dwords per parked Fp
+constexpr int FX_FP_PER_LANE = FX_FP2_TOTAL * SCRATCH_FP_PER_FP2;
+constexpr int FX_DWORDS_PER_LANE = FX_FP_PER_LANE * LANE_SCRATCH_DWORDS;         // 14 dwords per parked Fp
+BLS_HD LaneScratch fx_lane_scratch(uint32_t* buf, size_t lanes, size_t lane) { return lane_scratch(buf, lanes, lane, FX_FP_PER_LANE); }
 
 struct FexpScratch {
   LaneScratch ls;          // stage values, lane-sliced

@@ -721,31 +721,43 @@ BLS_HD void raw_fp_store(uint32_t* p, const FpR& a) {
   for (int i = 0; i < NL; ++i) p[i] = a.l[i];
 }
 
-// Lane-sliced scratch for multi-kernel pipelines (final exponentiation stages): value k of lane `lane` keeps its 14 limbs
-// as four 16-byte quarters at  base[((4 k + q) * lanes + lane) * 4 ..],  so that one store instruction of a wave writes
-// 64 consecutive 16-byte pieces (fully coalesced), whatever the number of values per lane.
+// Lane-sliced scratch for multi-kernel pipelines (final exponentiation stages): value k of lane `lane` keeps its 14 limbs as three
+// 16-byte quarters at  base[((3 k + q) * lanes + lane) * 4 ..]  and the two top limbs as one 8-byte piece at  top[(k * lanes + lane) * 2 ..]
+// (the `top` plane follows the quarter planes of ALL values), so that one store instruction of a wave writes 64 consecutive 16-byte
+// (8-byte) pieces -- fully coalesced, whatever the number of values per lane -- and a parked value costs 56 bytes, not 64.
+constexpr int LANE_SCRATCH_DWORDS = NL;      // per parked Fp
 struct LaneScratch {
   uint32_t* base;
+  uint32_t* top;
   size_t lanes, lane;
   BLS_HD void put(int k, const FpR& a) const {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint32_t* d = base + (((size_t)(4 * k + q)) * lanes + lane) * 4;
+    for (int q = 0; q < 3; ++q) {
+      uint32_t* d = base + (((size_t)(3 * k + q)) * lanes + lane) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = (4 * q + j < NL) ? a.l[4 * q + j] : 0u;
+      for (int j = 0; j < 4; ++j) d[j] = a.l[4 * q + j];
     }
+    uint32_t* t = top + ((size_t)k * lanes + lane) * 2;
+    t[0] = a.l[12]; t[1] = a.l[13];
   }
   BLS_HD FpR get(int k) const {
     FpR r;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t* d = base + (((size_t)(4 * k + q)) * lanes + lane) * 4;
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t* d = base + (((size_t)(3 * k + q)) * lanes + lane) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (4 * q + j < NL) r.l[4 * q + j] = d[j];
+      for (int j = 0; j < 4; ++j) r.l[4 * q + j] = d[j];
     }
+    const uint32_t* t = top + ((size_t)k * lanes + lane) * 2;
+    r.l[12] = t[0]; r.l[13] = t[1];
     return r;
   }
 };
+static_assert(NL == 14, "LaneScratch layout: three quarters and a pair");
+// nvals = values per lane the buffer was sized for (LANE_SCRATCH_DWORDS * nvals * lanes dwords)
+BLS_HD LaneScratch lane_scratch(uint32_t* buf, size_t lanes, size_t lane, size_t nvals) {
+  return LaneScratch{buf, buf + 12 * nvals * lanes, lanes, lane};
+}
 
 // Square-root candidate a^((p+1)/4) (p = 3 mod 4); the caller checks candidate^2 == a.
 template <int L, int V>

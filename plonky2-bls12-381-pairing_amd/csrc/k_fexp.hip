@@ -60,7 +60,7 @@ k_fexp_stage(const uint64_t* in, uint64_t* out, uint8_t* flags, uint32_t* __rest
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
-  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  const FexpScratch sc{fx_lane_scratch(scratch, lanes, gl), norm_raw, i};
   if constexpr (STAGE == 1) fexp_stage1(fp12_load(in + 72 * i, form), sc);
   else if constexpr (STAGE == 2) fexp_stage2(sc);
   else if constexpr (STAGE == 3) fexp_stage3(sc);
@@ -78,7 +78,7 @@ k_fexp_norm_park(const uint64_t* __restrict__ in, uint32_t* __restrict__ scratch
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
-  const FpR nrm = fexp_norm_pass(fp12_load(in + 72 * i, form), LaneScratch{scratch, lanes, gl});
+  const FpR nrm = fexp_norm_pass(fp12_load(in + 72 * i, form), fx_lane_scratch(scratch, lanes, gl));
   if (lane_part() == 0) raw_fp_store(raw + i * RAW_FP_STRIDE, nrm);
 }
 
@@ -88,7 +88,7 @@ k_fexp_chain(uint32_t* __restrict__ scratch, uint32_t* __restrict__ norm_raw, si
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
-  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  const FexpScratch sc{fx_lane_scratch(scratch, lanes, gl), norm_raw, i};
   fexp_chain(fx_getx(sc.ls), sc);
 }
 

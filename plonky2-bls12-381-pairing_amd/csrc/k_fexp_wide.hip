@@ -18,7 +18,7 @@ k_fexp_stage6_wide(uint64_t* out, uint8_t* flags, uint32_t* __restrict__ scratch
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
-  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  const FexpScratch sc{fx_lane_scratch(scratch, lanes, gl), norm_raw, i};
   fp12_store(out + 72 * i, fexp_stage6(sc), form);
   if (flags && lane_part() == 0) flags[i] = 0;
 }
@@ -31,7 +31,7 @@ k_fexp_glue1_wide(const uint64_t* __restrict__ in, uint32_t* __restrict__ scratc
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
-  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  const FexpScratch sc{fx_lane_scratch(scratch, lanes, gl), norm_raw, i};
   fx_putx(sc.ls, compress(fexp_glue1(fp12_load(in + 72 * i, form), sc)));
 }
 __global__ void __launch_bounds__(BLS_MAX_BLOCK)
@@ -39,7 +39,7 @@ k_fexp_glue_wide(int stage, uint32_t* __restrict__ scratch, uint32_t* __restrict
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gl / LANES_PER_ELEM;
   if (i >= n) return;
-  const FexpScratch sc{LaneScratch{scratch, lanes, gl}, norm_raw, i};
+  const FexpScratch sc{fx_lane_scratch(scratch, lanes, gl), norm_raw, i};
   const Fp12R e = fexp_finish_exp(sc);                                   // E(previous value), fexp_stages.hip.h
   Fp12R x;
   if (stage == 5) {

@@ -607,6 +607,69 @@ BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, 
   }
   return fit<1, 2>(conj(f));
 }
+
+// ---- Mode A with generic Fq12 accumulators, one accumulator in registers and the other in LDS.
+// optimized_miller_loop (src/miller_loop_native_optimized.rs:81-127) carries TWO Fq12 accumulators, f_num and f_den (168 registers
+// per lane), next to R (42), Q (42) and P (42), and multiplies them as full Fq12 values four times per iteration; with an inlined
+// Fq12 product (~250 registers of operands and partial results) that does not fit 512 registers and k_miller_ref_opt_wide spilled
+// 1.4 KB per lane.  The two accumulators are never needed at the same time: the one that is not being multiplied waits in six LDS
+// slots and the two change places after every half-iteration -- which also makes the two halves ONE instruction stream (a run-time
+// loop over {numerator, denominator}) instead of two copies.  Q is re-read from the input array at the six addition steps.
+template <int LANES>
+BLS_HD void fp12_lds_exchange(Fp12R& cur, const LaneLds<LANES>& lds) {
+  Fp12R nx;
+  nx.c0.c0 = Fp2R(lds.get(0)); nx.c0.c1 = Fp2R(lds.get(1)); nx.c0.c2 = Fp2R(lds.get(2));
+  nx.c1.c0 = Fp2R(lds.get(3)); nx.c1.c1 = Fp2R(lds.get(4)); nx.c1.c2 = Fp2R(lds.get(5));
+  lds.put(0, cur.c0.c0.v); lds.put(1, cur.c0.c1.v); lds.put(2, cur.c0.c2.v);
+  lds.put(3, cur.c1.c0.v); lds.put(4, cur.c1.c1.v); lds.put(5, cur.c1.c2.v);
+  cur = nx;
+}
+constexpr size_t ref_opt_lds_bytes_per_lane() { return 6 * 64; }
+
+template <int LANES>
+BLS_HD Fp12R miller_ref_opt_generic_lds(const G1Jac& p, const uint64_t* g2w, int form, const LaneLds<LANES>& lds, uint8_t& flags) {
+  G2Jac r = g2_jac_load(g2w, form);
+  flags = 0;
+  Fp12R cur = fp12_one();                                                  // f_num; f_den = 1 waits in LDS
+  lds.put(0, cur.c0.c0.v); lds.put(1, cur.c0.c1.v); lds.put(2, cur.c0.c2.v);
+  lds.put(3, cur.c1.c0.v); lds.put(4, cur.c1.c1.v); lds.put(5, cur.c1.c2.v);
+  for (int i = 0; i < 64; ++i) {                                           // :89, bit i of BLS_X, LSB first
+    const LineND t = line_tangent(r, p);                                   // :90
+#ifdef BLS_REFOPT_PARK_R
+    lds.put(6, r.x.v); lds.put(7, r.y.v); lds.put(8, r.z.v);
+    phase_fence();
+#endif
+#pragma clang loop unroll(disable)
+    for (int h = 0; h < 2; ++h) {                                          // h = 0: f_num (:91), h = 1: f_den (:92)
+      const Fp2R c = select(h == 0, t.n, t.d);
+      cur = mul_call(sqr_via_mul(cur), embed_fp2(c));
+      fp12_lds_exchange(cur, lds);
+    }
+#ifdef BLS_REFOPT_PARK_R
+    phase_fence();
+    r.x = Fp2R(lds.get(6)); r.y = Fp2R(lds.get(7)); r.z = Fp2R(lds.get(8));
+#endif
+    r = g2_jac_add(r, r);                                                  // :93
+    if ((BLS_X_PARAM >> i) & 1ull) {
+      const G2Jac q = g2_jac_load(g2w, form);
+      const LineND cl = line_chord(r, q, p);                               // :95
+#pragma clang loop unroll(disable)
+      for (int h = 0; h < 2; ++h) {                                        // :96, :97
+        const Fp2R c = select(h == 0, cl.n, cl.d);
+        cur = mul_call(cur, embed_fp2(c));
+        fp12_lds_exchange(cur, lds);
+      }
+      r = g2_jac_add(r, q);                                                // :98
+    }
+  }
+  const Fp12R f_num = cur;
+  Fp12R f_den;
+  f_den.c0.c0 = Fp2R(lds.get(0)); f_den.c0.c1 = Fp2R(lds.get(1)); f_den.c0.c2 = Fp2R(lds.get(2));
+  f_den.c1.c0 = Fp2R(lds.get(3)); f_den.c1.c1 = Fp2R(lds.get(4)); f_den.c1.c2 = Fp2R(lds.get(5));
+  if (is_zero(f_den)) { flags |= FLAG_DEN_ZERO; }                          // :102 panics in the reference
+  const Fp12R f = mul_call(f_num, inv(f_den));                             // :102
+  return mul_call(f, f);                                                   // :116-121
+}
 #endif
 
 }  // namespace bls

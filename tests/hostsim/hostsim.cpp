@@ -147,7 +147,7 @@ static int final_exp_staged(int form, const uint64_t* a, uint64_t* out, size_t n
   uint32_t* raw = (uint32_t*)calloc(n ? n : 1, RAW_FP_STRIDE * sizeof(uint32_t));
   uint32_t* scratch = (uint32_t*)calloc((n ? n : 1) * (size_t)FX_DWORDS_PER_LANE, sizeof(uint32_t));
   if (!raw || !scratch) return 2;
-  auto sc = [&](size_t i) { return FexpScratch{LaneScratch{scratch, n, i}, raw, i}; };
+  auto sc = [&](size_t i) { return FexpScratch{fx_lane_scratch(scratch, n, i), raw, i}; };
   for (size_t i = 0; i < n; ++i) raw_fp_store(raw + i * RAW_FP_STRIDE, fexp_norm_pass(fp12_load(a + 72 * i, form), sc(i).ls));
   batch_inv_raw(raw, n);
   if (split) {
