@@ -91,7 +91,9 @@ BLS_HD Jac<F> jac_double(const Jac<F>& p) {
   return r;
 }
 
-BLS_HD_NOINLINE G2Jac jac_double_call(const G2Jac& p) { return jac_double(p); }
+// BLS_FN_COLD (tower.hip.h): a real function by default; inlined in translation units compiled with BLS_COLD_INLINE=1, where arguments
+// and results then stay in registers instead of travelling through call frames in the private segment
+BLS_FN_COLD G2Jac jac_double_call(const G2Jac& p) { return jac_double(p); }
 BLS_HD_NOINLINE G1Jac jac_double_call(const G1Jac& p) { return jac_double(p); }
 
 // ark-ec 0.4.2 `impl AddAssign<&Self> for Projective` (EFD add-2007-bl) [third party; SURVEY App. A.3]
@@ -115,8 +117,11 @@ BLS_HD Jac<F> jac_add(const Jac<F>& p1, const Jac<F>& p2) {
   o.z = fit<1, 2>(fmul(sub(sub(fsqr(add(p1.z, p2.z)), Z1Z1), Z2Z2), H));
   return o;
 }
+// `R + R` (opt.rs:93): arkworks' add_assign finds U1 == U2, S1 == S2 and falls through to double_in_place (infinity stays infinity on
+// either path), so the doubling formulas ARE what the reference computes for this call; the addition formulas' common part
+// (two squarings, six products spent on discovering that the operands are equal) is not repeated here.
 BLS_HD G2Jac g2_jac_double(const G2Jac& p) { return jac_double_call(p); }
-BLS_HD_NOINLINE G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) { return jac_add(p1, p2); }
+BLS_FN_COLD G2Jac g2_jac_add(const G2Jac& p1, const G2Jac& p2) { return jac_add(p1, p2); }
 
 // Point helpers around the pairing (the reference's curve types: src/fields_as_trees/g2_curve.rs:29-166,
 // g1_curve.rs:22-110; arkworks `Projective` equality / normalisation [third party]).
@@ -199,7 +204,7 @@ BLS_HD LineND line_tail(const Fp2<Ln, Vn>& num, const Fp2<Ld, Vd>& den, const G2
 
 // tangent branch, taken unconditionally for the (R, R) call: num = y z - y z and den = x z - x z are exactly
 // zero, so the reference always lands in `else if lambda_numerator == zero` (:38-61)
-BLS_HD_NOINLINE LineND line_tangent(const G2Jac& q1, const G1Jac& p) {
+BLS_FN_COLD LineND line_tangent(const G2Jac& q1, const G1Jac& p) {
   const Fp2R xx = sqr(q1.x);
   const auto num = add(dbl(xx), xx);                               // 3 x1^2        (:39)
   const auto den = dbl(mul(q1.y, q1.z));                           // 2 y1 z1       (:40)
@@ -207,7 +212,7 @@ BLS_HD_NOINLINE LineND line_tangent(const G2Jac& q1, const G1Jac& p) {
 }
 
 // general call (R, Q): three-way branch of :14-77
-BLS_HD_NOINLINE LineND line_chord(const G2Jac& q1, const G2Jac& q2, const G1Jac& p) {
+BLS_FN_COLD LineND line_chord(const G2Jac& q1, const G2Jac& q2, const G1Jac& p) {
   const auto num = fit<1, 2>(sub(mul(q2.y, q1.z), mul(q1.y, q2.z)));   // :14
   const auto den = fit<1, 2>(sub(mul(q2.x, q1.z), mul(q1.x, q2.z)));   // :15
   if (!is_zero(den)) return line_tail(num, den, q1, p);                 // :16-37
@@ -218,7 +223,35 @@ BLS_HD_NOINLINE LineND line_chord(const G2Jac& q1, const G2Jac& q2, const G1Jac&
   return r;
 }
 
-BLS_HD Fp12R sqr_via_mul(const Fp12R& a) { return mul_call(a, a); }   // the reference squares with `f * f`
+// the reference squares its accumulators with the generic product, `f_num * f_num` (:91-92).  The value of a * a is the value of
+// the Fq12 squaring formula (fq12_target_tree.rs:143-155: two Fq6 products instead of three), so that is what runs; the generic
+// product stays selectable for A/B (BLS_REF_OPT_SQR_GENERIC=1, tools/kbench/kb_refopt.hip).
+#ifndef BLS_REF_OPT_SQR_GENERIC
+#define BLS_REF_OPT_SQR_GENERIC 0
+#endif
+BLS_HD Fp12R sqr_via_mul(const Fp12R& a) {
+#if BLS_REF_OPT_SQR_GENERIC
+  return mul_call(a, a);
+#else
+  return sqr_call(a);
+#endif
+}
+// a * Fq12::new(Fq6::new(c, 0, 0), Fq6::zero()) -- the product of the reference's generic `*` with an embedded Fp2 value
+// (:91-97), written without the partial products that meet the embedding's structural zeros: every Fp2 coefficient times c.
+// Same field element as mul_call(a, embed_fp2(c)), hence the same bits; the accumulators stay full Fq12 values.
+#ifndef BLS_REF_OPT_EMBED_GENERIC        // 1: multiply by the embedded value with the generic Fq12 product (A/B, tools/kbench/kb_refopt.hip)
+#define BLS_REF_OPT_EMBED_GENERIC 0
+#endif
+BLS_HD Fp12R mul_by_embedded_fp2(const Fp12R& a, const Fp2R& c) {
+#if BLS_REF_OPT_EMBED_GENERIC
+  Fp12R e;
+  e.c0 = Fp6R(c, Fp2R(fp2_zero()), Fp2R(fp2_zero()));
+  e.c1 = Fp6R(fp6_zero());
+  return mul_call(a, e);
+#else
+  return Fp12R(Fp6R(mul(a.c0.c0, c), mul(a.c0.c1, c), mul(a.c0.c2, c)), Fp6R(mul(a.c1.c0, c), mul(a.c1.c1, c), mul(a.c1.c2, c)));
+#endif
+}
 BLS_HD Fp12R embed_fp2(const Fp2R& v) {        // Fq12::new(Fq6::new(v, 0, 0), Fq6::zero())  (:18-36)
   Fp12R r;
   r.c0 = Fp6R(v, Fp2R(fp2_zero()), Fp2R(fp2_zero()));
@@ -236,13 +269,13 @@ BLS_HD Fp12R miller_ref_opt(const G1Jac& p, const G2Jac& q, uint8_t& flags) {
     Fp12R f_num = fp12_one(), f_den = fp12_one();
     for (int i = 0; i < 64; ++i) {                                        // :89, bit i of BLS_X, LSB first
       const LineND t = line_tangent(r, p);                                // :90
-      f_num = mul_call(sqr_via_mul(f_num), embed_fp2(t.n));               // :91
-      f_den = mul_call(sqr_via_mul(f_den), embed_fp2(t.d));               // :92
-      r = g2_jac_add(r, r);                                               // :93
+      f_num = mul_by_embedded_fp2(sqr_via_mul(f_num), t.n);               // :91
+      f_den = mul_by_embedded_fp2(sqr_via_mul(f_den), t.d);               // :92
+      r = g2_jac_double(r);                                                  // :93
       if ((BLS_X_PARAM >> i) & 1ull) {
         const LineND c = line_chord(r, q, p);                             // :95
-        f_num = mul_call(f_num, embed_fp2(c.n));                          // :96
-        f_den = mul_call(f_den, embed_fp2(c.d));                          // :97
+        f_num = mul_by_embedded_fp2(f_num, c.n);                          // :96
+        f_den = mul_by_embedded_fp2(f_den, c.d);                          // :97
         r = g2_jac_add(r, q);                                             // :98
       }
     }
@@ -255,7 +288,7 @@ BLS_HD Fp12R miller_ref_opt(const G1Jac& p, const G2Jac& q, uint8_t& flags) {
       const LineND t = line_tangent(r, p);
       f_num = mul(sqr(f_num), t.n);
       f_den = mul(sqr(f_den), t.d);
-      r = g2_jac_add(r, r);
+      r = g2_jac_double(r);   
       if ((BLS_X_PARAM >> i) & 1ull) {
         const LineND c = line_chord(r, q, p);
         f_num = mul(f_num, c.n);
@@ -642,21 +675,21 @@ BLS_HD Fp12R miller_ref_opt_generic_lds(const G1Jac& p, const uint64_t* g2w, int
 #pragma clang loop unroll(disable)
     for (int h = 0; h < 2; ++h) {                                          // h = 0: f_num (:91), h = 1: f_den (:92)
       const Fp2R c = select(h == 0, t.n, t.d);
-      cur = mul_call(sqr_via_mul(cur), embed_fp2(c));
+      cur = mul_by_embedded_fp2(sqr_via_mul(cur), c);
       fp12_lds_exchange(cur, lds);
     }
 #ifdef BLS_REFOPT_PARK_R
     phase_fence();
     r.x = Fp2R(lds.get(6)); r.y = Fp2R(lds.get(7)); r.z = Fp2R(lds.get(8));
 #endif
-    r = g2_jac_add(r, r);                                                  // :93
+    r = g2_jac_double(r);                                                     // :93
     if ((BLS_X_PARAM >> i) & 1ull) {
       const G2Jac q = g2_jac_load(g2w, form);
       const LineND cl = line_chord(r, q, p);                               // :95
 #pragma clang loop unroll(disable)
       for (int h = 0; h < 2; ++h) {                                        // :96, :97
         const Fp2R c = select(h == 0, cl.n, cl.d);
-        cur = mul_call(cur, embed_fp2(c));
+        cur = mul_by_embedded_fp2(cur, c);
         fp12_lds_exchange(cur, lds);
       }
       r = g2_jac_add(r, q);                                                // :98

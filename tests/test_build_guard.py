@@ -86,3 +86,14 @@ def test_current_build_has_no_reversed_operand_dpp_and_disables_the_combiner():
         assert chk.rev_dpp_uses(f) == [], f
     mk = open(os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "Makefile")).read()
     assert "-amdgpu-dpp-combine=false" in mk
+
+
+def test_design_kernel_table_matches_the_build():
+    """DESIGN.md 3.4's resource table (registers, private segment, LDS, occupancy per kernel) is generated from the device assembly
+    of the current build: a kernel change that is not followed by `python tools/kernel_table.py --update-design` fails here, so the
+    document cannot drift from the binaries."""
+    import pytest
+    files = glob.glob(os.path.join(ROOT, "plonky2-bls12-381-pairing_amd", "build", "*", "*gfx950.s"))
+    if not files:
+        pytest.skip("no build directory (library built elsewhere)")
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "kernel_table.py"), "--check-design"]) == 0
