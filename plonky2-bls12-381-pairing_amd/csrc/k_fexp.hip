@@ -82,7 +82,7 @@ k_fexp_norm_park(const uint64_t* __restrict__ in, uint32_t* __restrict__ scratch
   if (lane_part() == 0) raw_fp_store(raw + i * RAW_FP_STRIDE, nrm);
 }
 
-// The squaring chain alone (split launch, after k_fexp_glue*_wide parked its input): 178 registers, no scratch.
+// The squaring chain alone (split launch, after k_fexp_glue*_wide parked its input): ~200 registers, no private segment.
 __global__ void __launch_bounds__(BLS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_fexp_chain(uint32_t* __restrict__ scratch, uint32_t* __restrict__ norm_raw, size_t n, size_t lanes) {
   const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,7 +42,7 @@ k_multi_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2,
 }
 
 namespace bls_launch {
-// A full pairing is this Miller kernel (one wave per SIMD, ~460 registers per lane, no scratch) followed by a final
+// A full pairing is this Miller kernel (one wave per SIMD, all 512 registers per lane, 0-88 B of private segment for one pair: DESIGN 3.4 table) followed by a final
 // exponentiation in place on `out` (k_fexp.hip: its own translation unit, compiled for two waves per SIMD, where it
 // runs ~15 % faster than inside a fused kernel).  The intermediate Fq12 costs 2 x 576 B of HBM traffic per pairing.
 void BLS_CAT(multi_k, BLS_K)(bool hom, const uint64_t* g1, const uint64_t* g2, size_t stride, uint64_t* out, uint8_t* flags, bool flags_or,
