@@ -77,7 +77,7 @@ enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_B
 enum { BLS381_INFO_LAST_FEXP_MODE = 100       /* BLS381_FEXP_SELF_CONTAINED / _BATCHED_INVERSION / _STAGED; -1: no final exponentiation */,
        BLS381_INFO_LAST_FEXP_PIPELINES = 101  /* part-batch pipelines of the staged form (1 for the other forms) */,
        BLS381_INFO_LAST_MILLER_HOMOGENEOUS = 102 /* 1: the Miller loops walked homogeneous-projective curve steps, 0: Alg. 26/27 */,
-       BLS381_INFO_LAST_MILLER_GROUP = 103    /* pairs per Miller launch (k for k <= 4, else 3: groups of three multiplied on device) */ };
+       BLS381_INFO_LAST_MILLER_GROUP = 103    /* pairs per Miller launch (k for k <= 3, else 3: groups of three multiplied on device) */ };
 enum { BLS381_FEXP_SELF_CONTAINED = 0,  /* one kernel, one Fermat inversion per element */
        BLS381_FEXP_BATCHED_INVERSION = 1, /* the Fp inversion under f^-1 (:175) from a batch-wide simultaneous inversion: three launches,
                                              64 B of context-owned device scratch per element */
@@ -156,7 +156,7 @@ int bls381_miller_ref_opt_batch_dev(bls381_ctx* ctx, const uint64_t* g1_jac, con
                                     uint64_t* out_fq12, uint8_t* flags, size_t n);
 
 /* Mode B: product over k pairs of optimal-ate Miller loops -- `multi_miller_loop(terms: &[(&G1Affine, &G2Affine)])`,
- * src/miller_loop_native.rs:154 -- for a slice of ANY length k >= 1.  Up to four pairs share one loop (one squaring per
+ * src/miller_loop_native.rs:154 -- for a slice of ANY length k >= 1.  Up to three pairs share one loop (one squaring per
  * iteration for all of them, :100-106); longer products run in groups of three whose Miller values are multiplied on the
  * device (the same field element: squaring distributes over the product), with one final exponentiation at the end.
  * g1_aff: n x k x 2 x 6, g2_aff: n x k x 2 x 2 x 6, out: n x 12 x 6. */

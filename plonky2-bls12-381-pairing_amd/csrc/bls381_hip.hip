@@ -30,7 +30,7 @@ struct bls381_ctx {
   size_t raw_scratch_elems = 0;
   uint32_t* stage_scratch = nullptr; // staged form: lane-sliced stage values (csrc/fexp_stages.hip.h)
   size_t stage_scratch_bytes = 0;
-  uint64_t* part_scratch = nullptr;  // products of more than four pairs: Miller value of the current group of pairs (n x 72 u64)
+  uint64_t* part_scratch = nullptr;  // products of more than three pairs: Miller value of the current group of pairs (n x 72 u64)
   size_t part_scratch_elems = 0;
   hipEvent_t part_done = nullptr;    // recorded behind the last launch that used part_scratch
   hipStream_t part_stream = nullptr;
@@ -339,8 +339,9 @@ int launch_ref_opt(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, uint64
   return BLS381_OK;
 }
 
-// Pairs per Miller launch for a product of k pairs: up to four pairs go in one launch (shared squarings); longer products
-// are cut into groups of three (the largest group whose state stays in registers), the groups' Miller values are multiplied
+// Pairs per Miller launch for a product of k pairs: up to three pairs go in one launch (shared squarings); longer products
+// are cut into groups of three (round 3 measured four pairs in one launch -- a kernel that calls its step routines -- at 34.0 ms per
+// 2^16 against 31.7 ms for 3 + 1; tools/time_multi_k.py), the groups' Miller values are multiplied
 // on the device (bit-identical to one shared loop: squaring distributes over the product) and ONE final exponentiation
 // follows -- `multi_miller_loop(terms: &[..])` takes a slice of any length (src/miller_loop_native.rs:154-212).
 constexpr size_t MULTI_GROUP = 3;
@@ -361,15 +362,15 @@ int launch_multi(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t k
   HIP_TRY(c, hipSetDevice(c->device));
   FexpPlan plan;
   if (FE) { const int rc = fexp_acquire(c, n, &plan); if (rc != BLS381_OK) return rc; }
-  if (k > 4) { const int rc = part_acquire(c, n); if (rc != BLS381_OK) return rc; }
+  if (k > MULTI_GROUP) { const int rc = part_acquire(c, n); if (rc != BLS381_OK) return rc; }
   int rc = BLS381_OK;
   {
     Timed t(c);
     const bool hom = FE && c->hom_miller;
     c->last_hom = hom ? 1 : 0;
-    c->last_group = (int)(k <= 4 ? k : MULTI_GROUP);
+    c->last_group = (int)(k <= MULTI_GROUP ? k : MULTI_GROUP);
     if (!FE) { c->last_fexp_mode = -1; c->last_fexp_pipes = -1; }
-    if (k <= 4) {
+    if (k <= MULTI_GROUP) {
       if (!bls_launch::multi(k, hom, g1, g2, k, out, flags, false, n, c->io_form, c->block, c->stream)) return BLS381_E_INVALID;
     } else {
       for (size_t first = 0; first < k; first += MULTI_GROUP) {

@@ -207,7 +207,6 @@ bool multi(size_t k, bool hom, const uint64_t* g1, const uint64_t* g2, size_t st
     case 1: multi_k1(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
     case 2: multi_k2(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
     case 3: multi_k3(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
-    case 4: multi_k4(hom, g1, g2, stride, out, flags, flags_or, n, form, block, s); return true;
     default: return false;
   }
 }

@@ -15,7 +15,7 @@ using namespace bls;
 static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n * bls::LANES_PER_ELEM + block - 1) / block); }
 
 #ifndef BLS_K
-#error "compile with -DBLS_K=1..4"
+#error "compile with -DBLS_K=1..3"
 #endif
 #define BLS_CAT2(a, b) a##b
 #define BLS_CAT(a, b) BLS_CAT2(a, b)

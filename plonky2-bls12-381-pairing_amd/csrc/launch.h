@@ -7,7 +7,7 @@ namespace bls_launch {
 // Mode A with generic Fq12 accumulators, one wave per SIMD, products inlined (k_ref_opt_wide.hip)
 void ref_opt_wide(const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
 void ref_opt(bool fp2_shortcut, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s);
-// k in 1..4 pairs per launch, read from arrays that hold `stride` >= k pairs per element (g1 / g2 point at the first pair of
+// k in 1..3 pairs per launch, read from arrays that hold `stride` >= k pairs per element (g1 / g2 point at the first pair of
 // element 0 to use); returns false for an unsupported k.  flags_or: OR into flags[] instead of overwriting it.
 // Miller loops only; a full pairing = this, then one of the final-exponentiation launches in place on `out`
 // hom: homogeneous-projective curve steps (only for results that go through the final exponentiation)
@@ -16,7 +16,6 @@ bool multi(size_t k, bool hom, const uint64_t* g1, const uint64_t* g2, size_t st
 void multi_k1(bool hom, const uint64_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, bool, size_t, int, int, hipStream_t);
 void multi_k2(bool hom, const uint64_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, bool, size_t, int, int, hipStream_t);
 void multi_k3(bool hom, const uint64_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, bool, size_t, int, int, hipStream_t);
-void multi_k4(bool hom, const uint64_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, bool, size_t, int, int, hipStream_t);
 // raw_scratch: n x 16 dwords for the split form (batched inversion), or nullptr for the self-contained kernel
 void final_exp(const uint64_t* in, uint64_t* out, uint8_t* flags, size_t n, int form, int block, hipStream_t s, uint32_t* raw_scratch);
 void fp_batch_inv_raw(uint32_t* raw, size_t n, hipStream_t s);

@@ -317,7 +317,7 @@ def test_mode_b_golden(engine):
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 9])
 def test_mode_b_vs_c_oracle_batch(engine, coracle, k):
     """Products of k pairs (`multi_miller_loop(terms: &[..])` takes any length, src/miller_loop_native.rs:154): one launch up to
-    k = 4 (k = 4 through the out-of-line homogeneous steps), groups of three multiplied on the device beyond; pairs at
+    k = 3, groups of three multiplied on the device beyond (k = 4 is 3 + 1, k = 7 is 3 + 3 + 1); pairs at
     infinity in the first and in a later group (their flag must survive the later groups' launches)."""
     n = 300 + k
     g1, g2 = synthetic_batch(n, seed=9000 + k, jacobian=False, k=k, pool=50)
