@@ -508,25 +508,26 @@ BLS_HD G2Aff g2_aff_load(const uint64_t* w, int form, bool& inf) {
 }
 
 #if BLS_LANES == 2
-// ---- the same loop with the per-pair state parked in LDS (device kernels, lane-pair layout).
-// What a lane must keep through an iteration of miller_ate is f (84 registers), and per pair R (42), Q (28) and P (28): with the
-// working set of the Fq12 squaring (~170) one pair just fits 512 registers, two or three do not -- the compiler then keeps r[], q[], p[]
-// in the private segment (1.0-1.4 KB per lane, walked with a run-time pair index) and a lone wave per SIMD waits out every scratch
-// access.  Here the pair index is a run-time loop by design and the state that is not being worked on lives in LDS:
-//   * P: one converted coordinate per lane (even lane x, odd lane y; both lanes read both) -- K slots;
-//   * R of the pairs that are not current: K - 1 slots of three values; the current R stays in registers and CHANGES PLACES with the
-//     slot of the pair that is next (the slots hold the pairs in FIFO order, so slot number = step count mod (K - 1));
-//   * Q: not kept at all -- the five addition steps of the loop re-read it from the input array (one conversion per coordinate).
-// A slot is 16 dwords per lane (14 used), lane-sliced in four 16-byte quarters like LaneScratch: every LDS instruction of a wave
-// moves 64 consecutive 16-byte pieces, no bank conflicts.  K = 3: (2 x 3 + 3) x 64 B = 576 B per lane, 36 KB per wave, four waves per CU.
+// ---- products of K >= 2 pairs on the device: the same loop with the idle pairs' R parked in LDS (lane-pair layout).
+// What a lane must keep through an iteration of miller_ate is f (84 registers) and, per pair, R (42), Q (28) and P (28); with the
+// working set of the Fq12 squaring (~170) one pair just fits 512 registers, two or three do not.  Left to itself the compiler keeps
+// r[], q[], p[] in the private segment (1.0-1.4 KB per lane) and walks them with a run-time pair index -- one copy of the step code,
+// but every pair-step starts by waiting for its R, P (and Q) to come back from scratch, alone on its SIMD: 91 ms per 2^18 three-pair
+// products where the one-pair kernel's instruction rate would give 71.  Here:
+//   * the pair index is a run-time loop by design (one copy of the step code);
+//   * R of the current pair is in registers and CHANGES PLACES with the next pair's in LDS after every step (the K - 1 slots hold
+//     the other pairs in FIFO order, so the slot to use is the step count mod K - 1): six 128-bit LDS instructions each way;
+//   * P and Q of ALL pairs stay in registers (AGPRs in practice) and the current pair's are picked by comparing the loop index --
+//     wave-uniform, 28 + 28 register moves.  Measured alternatives (tools/kbench/kb_multi.hip, 2^18 products, K = 3): P from LDS
+//     102 ms (an LDS load lands in VGPRs as whole 128-bit quads exactly where the line multiplication is at its register peak, and
+//     gets spilled at once), Q re-read from the input array at the five addition steps 73.9 ms, both in registers 72.3 ms.
+// A slot is 16 dwords per lane (14 used), lane-sliced in four 16-byte quarters: every LDS instruction of a wave moves 64 consecutive
+// 16-byte pieces, no bank conflicts; addresses are one per-lane base register plus immediate offsets (LANES is a compile-time
+// constant).  K = 3: 2 x 3 x 64 B = 384 B per lane, 24 KB per one-wave workgroup, four workgroups per CU.
 struct alignas(16) LdsQuad { uint32_t w[4]; };
-// LANES = lanes of the workgroup, a compile-time constant: slot addresses are then ONE per-lane base register plus immediate offsets
-// (ds_read_b128 / ds_write_b128 offset field) -- with a run-time stride the compiler hoists one address register per (slot, quarter)
-// out of the loop and spills them.
 template <int LANES>
 struct LaneLds {
   LdsQuad* mine;          // this lane's column:  base + lane
-  LdsQuad* pair0;         // the even lane of this lane's pair:  base + (lane & ~1)
   BLS_HD void put(int slot, const FpR& a) const {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -536,57 +537,44 @@ struct LaneLds {
       mine[(4 * slot + q) * LANES] = v;
     }
   }
-  static BLS_HD FpR get_at(const LdsQuad* col, int slot) {
+  BLS_HD FpR get(int slot) const {
     FpR r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const LdsQuad v = col[(4 * slot + q) * LANES];
+      const LdsQuad v = mine[(4 * slot + q) * LANES];
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (4 * q + j < NL) r.l[4 * q + j] = v.w[j];
     }
     return r;
   }
-  BLS_HD FpR get(int slot) const { return get_at(mine, slot); }
-  BLS_HD FpR get_even(int slot) const { return get_at(pair0, slot); }      // the value the even lane of the pair put
-  BLS_HD FpR get_odd(int slot) const { return get_at(pair0 + 1, slot); }   // ... the odd lane
 };
 template <int LANES>
-BLS_HD LaneLds<LANES> lane_lds(LdsQuad* base, unsigned lane) { return LaneLds<LANES>{base + lane, base + (lane & ~1u)}; }
-// scheduling fence: keeps the instruction scheduler from hoisting the next phase's loads above the current phase (register pressure)
+BLS_HD LaneLds<LANES> lane_lds(LdsQuad* base, unsigned lane) { return LaneLds<LANES>{base + lane}; }
+// Scheduling fence between the phases of a pair-step: without it the instruction scheduler pulls the next phase's LDS loads and
+// register picks up into the current phase and the allocator answers with a private segment of 1.8 KB instead of 0.5 KB (K = 3).
 BLS_HD void phase_fence() {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLS_LDS_NOFENCE)
+#if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-// compiler-level memory barrier: the LDS reads behind it are not hoisted out of the loop (P is loop-invariant data; hoisted it
-// would be live -- and spilled -- through the whole loop, which is what parking it in LDS is meant to avoid)
-BLS_HD void lds_reload_point() {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BLS_LDS_MEMBAR)
-  asm volatile("" ::: "memory");
-#endif
-}
-constexpr int miller_lds_slots(int k) { return 3 * (k - 1) + k; }            // per lane, 64 bytes each
+constexpr int miller_lds_slots(int k) { return 3 * (k - 1); }                // per lane, 64 bytes each
 constexpr size_t miller_lds_bytes_per_lane(int k) { return (size_t)miller_lds_slots(k) * 64; }
 
-// g1e / g2e: the element's first pair in the caller's arrays (12 / 24 u64 per pair); returns the Miller value, ORs the flag bits
+// g1e / g2e: the element's first pair in the caller's arrays (12 / 24 u64 per pair, pairs consecutive); returns the Miller value and
+// ORs the flag bits into fl
 template <int K, bool HOM, int LANES>
 BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, const LaneLds<LANES>& lds, uint8_t& fl) {
-  constexpr int P_BASE = 3 * (K - 1);
+  static_assert(K >= 2, "one pair: miller_ate");
   unsigned skip = 0;
+  G1Aff p_all[K]; G2Aff q_all[K];          // only ever indexed by constants (unrolled comparisons): registers, not memory
   G2Jac cur;
-#if defined(BLS_LDS_KEEP_P) || defined(BLS_LDS_KEEP_Q)
-  static_assert(K == 1, "experiment switches");
-  G1Aff p_reg; G2Aff q_reg;
-#endif
-  for (int j = 0; j < K; ++j) {
+  for (int j = 0; j < K; ++j) {            // (the compiler keeps this a loop: the conversions are one copy of code)
     bool i1, i2;
     const G1Aff p = g1_aff_load(g1e + 12 * j, form, i1);
     const G2Aff q = g2_aff_load(g2e + 24 * j, form, i2);
-#if defined(BLS_LDS_KEEP_P) || defined(BLS_LDS_KEEP_Q)
-    p_reg = p; q_reg = q;
-#endif
     if (i1 || i2) { skip |= 1u << j; fl |= FLAG_INFINITY; }
-    lds.put(P_BASE + j, lane_part() == 0 ? p.x : p.y);
+#pragma unroll
+    for (int t = 0; t < K; ++t) if (j == t) { p_all[t] = p; q_all[t] = q; }      // static indices only
     const Fp2R one = Fp2R(fp2_one());
     if (j == 0) { cur.x = q.x; cur.y = q.y; cur.z = one; }
     else { lds.put(3 * (j - 1) + 0, q.x.v); lds.put(3 * (j - 1) + 1, q.y.v); lds.put(3 * (j - 1) + 2, one.v); }
@@ -604,36 +592,28 @@ BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, 
         if (pass == 0) {
           l = HOM ? doubling_step_hom(cur) : doubling_step(cur);
         } else {
-#ifdef BLS_LDS_KEEP_Q
-          const G2Aff q = q_reg;
-#else
-          bool inf;
-          const G2Aff q = g2_aff_load(g2e + 24 * j, form, inf);
-#endif
+          G2Aff q = q_all[0];
+#pragma unroll
+          for (int t = 1; t < K; ++t) if (j == t) q = q_all[t];
           l = HOM ? addition_step_hom(cur, q) : addition_step(cur, q);
         }
         phase_fence();
         if (!((skip >> j) & 1u)) {
-          G1Aff p;
-#ifdef BLS_LDS_KEEP_P
-          p = p_reg;
-#else
-          lds_reload_point();
-          p.x = lds.get_even(P_BASE + j);
-          p.y = lds.get_odd(P_BASE + j);
-#endif
+          G1Aff p = p_all[0];
+#pragma unroll
+          for (int t = 1; t < K; ++t) if (j == t) p = p_all[t];
           // the very first line meets f = 1: no multiplication (a uniform branch; a skipped first pair leaves f = 1 for the next)
           f = (BLS_MILLER_PEEL && b == 61 && pass == 0 && j == 0) ? line_value(l, p) : ell(f, l, p);
         }
         phase_fence();
-        if (K > 1) {                                // the current R changes places with the next pair's
+        {                                           // the current R changes places with the next pair's
           G2Jac nx;
           nx.x = Fp2R(lds.get(3 * slot + 0)); nx.y = Fp2R(lds.get(3 * slot + 1)); nx.z = Fp2R(lds.get(3 * slot + 2));
           lds.put(3 * slot + 0, cur.x.v); lds.put(3 * slot + 1, cur.y.v); lds.put(3 * slot + 2, cur.z.v);
           cur = nx;
           slot = (slot + 1 == K - 1) ? 0 : slot + 1;
-          phase_fence();
         }
+        phase_fence();
       }
     }
     if (!last) f = sqr(f);
@@ -668,20 +648,12 @@ BLS_HD Fp12R miller_ref_opt_generic_lds(const G1Jac& p, const uint64_t* g2w, int
   lds.put(3, cur.c1.c0.v); lds.put(4, cur.c1.c1.v); lds.put(5, cur.c1.c2.v);
   for (int i = 0; i < 64; ++i) {                                           // :89, bit i of BLS_X, LSB first
     const LineND t = line_tangent(r, p);                                   // :90
-#ifdef BLS_REFOPT_PARK_R
-    lds.put(6, r.x.v); lds.put(7, r.y.v); lds.put(8, r.z.v);
-    phase_fence();
-#endif
 #pragma clang loop unroll(disable)
     for (int h = 0; h < 2; ++h) {                                          // h = 0: f_num (:91), h = 1: f_den (:92)
       const Fp2R c = select(h == 0, t.n, t.d);
       cur = mul_by_embedded_fp2(sqr_via_mul(cur), c);
       fp12_lds_exchange(cur, lds);
     }
-#ifdef BLS_REFOPT_PARK_R
-    phase_fence();
-    r.x = Fp2R(lds.get(6)); r.y = Fp2R(lds.get(7)); r.z = Fp2R(lds.get(8));
-#endif
     r = g2_jac_double(r);                                                     // :93
     if ((BLS_X_PARAM >> i) & 1ull) {
       const G2Jac q = g2_jac_load(g2w, form);

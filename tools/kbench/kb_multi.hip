@@ -1,5 +1,6 @@
 // Developer tool: the Miller kernel for products of K pairs, register/scratch form (miller_ate) against the LDS form
-// (miller_ate_lds), same inputs, checksums must agree.   KB_K = 1..3, KB_HOM = true/false
+// (miller_ate_lds), same inputs, checksums must agree.   KB_K = 2..3, KB_HOM = true/false
+// (the P-in-LDS / Q-re-read variants of round 3 are in the git history of csrc/pairing.hip.h: DESIGN 3.8 has their numbers)
 //   KB_SRC=kb_multi.hip tools/kbench/build_variant.sh multi3 -DKB_K=3
 #include <hip/hip_runtime.h>
 #include <cstdio>
