@@ -60,7 +60,10 @@ enum {
   BLS381_FLAG_TRUE = 32     /* point predicates (BLS381_POINT_EQ, BLS381_POINT_IS_ON_CURVE): the predicate holds */
 };
 
-enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1, BLS381_OPT_BLOCK_SIZE = 2,
+enum { BLS381_OPT_IO_FORM = 0, BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1,
+       BLS381_OPT_BLOCK_SIZE = 2 /* lanes per workgroup: 64 (default), 128 or 256.  No measurable effect (nothing is shared between lanes);
+          the kernels that park state in LDS -- Miller loops of two and three pairs, Mode A with Fq12 accumulators -- always run one
+          wave per workgroup, and the prepared-coefficient kernels 256 lanes */,
        BLS381_OPT_FEXP_MODE = 3 /* how the final exponentiation (src/fields_as_trees/miller_loop.rs:128-178) is run; same output bits */,
        BLS381_OPT_FEXP_PIPELINES = 4 /* staged mode: 1..4 part-batch pipelines on internal streams; 0 (default) = automatic: 2 from 2^18
           elements, 1 below; an explicit setting applies from 2^14 elements */,
