@@ -233,6 +233,10 @@ constexpr int SCRATCH_FP_PER_FP2 = 1;
 BLS_HD void fp2_scratch_put(const LaneScratch& s, int idx, const Fp2R& a) { s.put(idx, a.v); }
 BLS_HD Fp2R fp2_scratch_get(const LaneScratch& s, int idx) { return Fp2R(s.get(idx)); }
 
+// Fp2 number `idx` of this lane in a per-lane slot store with put(slot, FpR) / get(slot) (LaneLds, pairing.hip.h): one Fp per lane
+template <class Store> BLS_HD void fp2_slot_put(const Store& s, int idx, const Fp2R& a) { s.put(idx, a.v); }
+template <class Store> BLS_HD Fp2R fp2_slot_get(const Store& s, int idx) { return Fp2R(s.get(idx)); }
+
 // pair-wide AND of a per-lane predicate
 BLS_HD bool pair_all(bool z) { return (dpp_swap(z ? 1u : 0u) & (z ? 1u : 0u)) != 0; }
 

@@ -145,6 +145,8 @@ BLS_HD_NOINLINE Fp2R inv(const Fp2<L, V>& a_in) {
 
 // Fp2 number `idx` of this element in a LaneScratch (two Fp per Fp2 on the one lane)
 constexpr int SCRATCH_FP_PER_FP2 = 2;
+template <class Store> BLS_HD void fp2_slot_put(const Store& s, int idx, const Fp2R& a) { s.put(2 * idx, a.c0); s.put(2 * idx + 1, a.c1); }
+template <class Store> BLS_HD Fp2R fp2_slot_get(const Store& s, int idx) { return Fp2R(s.get(2 * idx), s.get(2 * idx + 1)); }
 BLS_HD void fp2_scratch_put(const LaneScratch& s, int idx, const Fp2R& a) { s.put(2 * idx, a.c0); s.put(2 * idx + 1, a.c1); }
 BLS_HD Fp2R fp2_scratch_get(const LaneScratch& s, int idx) { return Fp2R(s.get(2 * idx), s.get(2 * idx + 1)); }
 

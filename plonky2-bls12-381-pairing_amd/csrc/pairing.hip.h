@@ -507,8 +507,8 @@ BLS_HD G2Aff g2_aff_load(const uint64_t* w, int form, bool& inf) {
   G2Aff q; q.x = fp2_load(w, form); q.y = fp2_load(w + 12, form); return q;
 }
 
-#if BLS_LANES == 2
-// ---- products of K >= 2 pairs on the device: the same loop with the idle pairs' R parked in LDS (lane-pair layout).
+// ---- products of K >= 2 pairs on the device: the same loop with the idle pairs' R parked in LDS.
+// (Written against the Fp2 backend's slot helpers, so the host build runs the same source over a plain buffer: tests/hostsim.)
 // What a lane must keep through an iteration of miller_ate is f (84 registers) and, per pair, R (42), Q (28) and P (28); with the
 // working set of the Fq12 squaring (~170) one pair just fits 512 registers, two or three do not.  Left to itself the compiler keeps
 // r[], q[], p[] in the private segment (1.0-1.4 KB per lane) and walks them with a run-time pair index -- one copy of the step code,
@@ -557,7 +557,7 @@ BLS_HD void phase_fence() {
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-constexpr int miller_lds_slots(int k) { return 3 * (k - 1); }                // per lane, 64 bytes each
+constexpr int miller_lds_slots(int k) { return 3 * (k - 1) * SCRATCH_FP_PER_FP2; }     // per lane, 64 bytes each (one Fp per slot)
 constexpr size_t miller_lds_bytes_per_lane(int k) { return (size_t)miller_lds_slots(k) * 64; }
 
 // g1e / g2e: the element's first pair in the caller's arrays (12 / 24 u64 per pair, pairs consecutive); returns the Miller value and
@@ -577,7 +577,7 @@ BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, 
     for (int t = 0; t < K; ++t) if (j == t) { p_all[t] = p; q_all[t] = q; }      // static indices only
     const Fp2R one = Fp2R(fp2_one());
     if (j == 0) { cur.x = q.x; cur.y = q.y; cur.z = one; }
-    else { lds.put(3 * (j - 1) + 0, q.x.v); lds.put(3 * (j - 1) + 1, q.y.v); lds.put(3 * (j - 1) + 2, one.v); }
+    else { fp2_slot_put(lds, 3 * (j - 1) + 0, q.x); fp2_slot_put(lds, 3 * (j - 1) + 1, q.y); fp2_slot_put(lds, 3 * (j - 1) + 2, one); }
   }
   Fp12R f = fp12_one();
   int slot = 0;                                    // the slot that holds the pair after the current one
@@ -608,8 +608,8 @@ BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, 
         phase_fence();
         {                                           // the current R changes places with the next pair's
           G2Jac nx;
-          nx.x = Fp2R(lds.get(3 * slot + 0)); nx.y = Fp2R(lds.get(3 * slot + 1)); nx.z = Fp2R(lds.get(3 * slot + 2));
-          lds.put(3 * slot + 0, cur.x.v); lds.put(3 * slot + 1, cur.y.v); lds.put(3 * slot + 2, cur.z.v);
+          nx.x = fp2_slot_get(lds, 3 * slot + 0); nx.y = fp2_slot_get(lds, 3 * slot + 1); nx.z = fp2_slot_get(lds, 3 * slot + 2);
+          fp2_slot_put(lds, 3 * slot + 0, cur.x); fp2_slot_put(lds, 3 * slot + 1, cur.y); fp2_slot_put(lds, 3 * slot + 2, cur.z);
           cur = nx;
           slot = (slot + 1 == K - 1) ? 0 : slot + 1;
         }
@@ -629,23 +629,29 @@ BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, 
 // slots and the two change places after every half-iteration -- which also makes the two halves ONE instruction stream (a run-time
 // loop over {numerator, denominator}) instead of two copies.  Q is re-read from the input array at the six addition steps.
 template <int LANES>
+BLS_HD void fp12_lds_put(const LaneLds<LANES>& lds, const Fp12R& a) {
+  fp2_slot_put(lds, 0, a.c0.c0); fp2_slot_put(lds, 1, a.c0.c1); fp2_slot_put(lds, 2, a.c0.c2);
+  fp2_slot_put(lds, 3, a.c1.c0); fp2_slot_put(lds, 4, a.c1.c1); fp2_slot_put(lds, 5, a.c1.c2);
+}
+template <int LANES>
+BLS_HD Fp12R fp12_lds_get(const LaneLds<LANES>& lds) {
+  return Fp12R(Fp6R(fp2_slot_get(lds, 0), fp2_slot_get(lds, 1), fp2_slot_get(lds, 2)),
+               Fp6R(fp2_slot_get(lds, 3), fp2_slot_get(lds, 4), fp2_slot_get(lds, 5)));
+}
+template <int LANES>
 BLS_HD void fp12_lds_exchange(Fp12R& cur, const LaneLds<LANES>& lds) {
-  Fp12R nx;
-  nx.c0.c0 = Fp2R(lds.get(0)); nx.c0.c1 = Fp2R(lds.get(1)); nx.c0.c2 = Fp2R(lds.get(2));
-  nx.c1.c0 = Fp2R(lds.get(3)); nx.c1.c1 = Fp2R(lds.get(4)); nx.c1.c2 = Fp2R(lds.get(5));
-  lds.put(0, cur.c0.c0.v); lds.put(1, cur.c0.c1.v); lds.put(2, cur.c0.c2.v);
-  lds.put(3, cur.c1.c0.v); lds.put(4, cur.c1.c1.v); lds.put(5, cur.c1.c2.v);
+  const Fp12R nx = fp12_lds_get(lds);
+  fp12_lds_put(lds, cur);
   cur = nx;
 }
-constexpr size_t ref_opt_lds_bytes_per_lane() { return 6 * 64; }
+constexpr size_t ref_opt_lds_bytes_per_lane() { return 6 * SCRATCH_FP_PER_FP2 * 64; }
 
 template <int LANES>
 BLS_HD Fp12R miller_ref_opt_generic_lds(const G1Jac& p, const uint64_t* g2w, int form, const LaneLds<LANES>& lds, uint8_t& flags) {
   G2Jac r = g2_jac_load(g2w, form);
   flags = 0;
   Fp12R cur = fp12_one();                                                  // f_num; f_den = 1 waits in LDS
-  lds.put(0, cur.c0.c0.v); lds.put(1, cur.c0.c1.v); lds.put(2, cur.c0.c2.v);
-  lds.put(3, cur.c1.c0.v); lds.put(4, cur.c1.c1.v); lds.put(5, cur.c1.c2.v);
+  fp12_lds_put(lds, cur);
   for (int i = 0; i < 64; ++i) {                                           // :89, bit i of BLS_X, LSB first
     const LineND t = line_tangent(r, p);                                   // :90
 #pragma clang loop unroll(disable)
@@ -668,13 +674,10 @@ BLS_HD Fp12R miller_ref_opt_generic_lds(const G1Jac& p, const uint64_t* g2w, int
     }
   }
   const Fp12R f_num = cur;
-  Fp12R f_den;
-  f_den.c0.c0 = Fp2R(lds.get(0)); f_den.c0.c1 = Fp2R(lds.get(1)); f_den.c0.c2 = Fp2R(lds.get(2));
-  f_den.c1.c0 = Fp2R(lds.get(3)); f_den.c1.c1 = Fp2R(lds.get(4)); f_den.c1.c2 = Fp2R(lds.get(5));
+  const Fp12R f_den = fp12_lds_get(lds);
   if (is_zero(f_den)) { flags |= FLAG_DEN_ZERO; }                          // :102 panics in the reference
   const Fp12R f = mul_call(f_num, inv(f_den));                             // :102
   return mul_call(f, f);                                                   // :116-121
 }
-#endif
 
 }  // namespace bls

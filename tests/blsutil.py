@@ -175,6 +175,25 @@ class HostSim:
         assert rc == 0
         return out, flags
 
+    def miller_ref_opt_lds(self, g1, g2, form=IO_ARK_MONT):
+        """Mode A as k_miller_ref_opt_wide runs it: one Fq12 accumulator in registers, the other in (here: a plain buffer standing in for) LDS"""
+        n = len(g1) // 18
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        rc = self.lib.hostsim_miller_ref_opt_lds(form, _ptr(g1), _ptr(g2), _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n))
+        assert rc == 0
+        return out, flags
+
+    def multi_miller_lds(self, g1, g2, k, final_exp=False, form=IO_ARK_MONT):
+        """products of k = 2, 3 pairs as k_multi_miller<2|3> runs them: the idle pairs' R in the slot store (miller_ate_lds)"""
+        n = len(g1) // (12 * k)
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        rc = self.lib.hostsim_multi_miller_lds(form, int(final_exp), _ptr(g1), _ptr(g2), ctypes.c_size_t(k), _ptr(out),
+                                               _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n))
+        assert rc == 0
+        return out, flags
+
     def multi_miller(self, g1, g2, k=1, final_exp=False, form=IO_ARK_MONT):
         n = len(g1) // (12 * k)
         out = np.zeros(n * 72, dtype=np.uint64)

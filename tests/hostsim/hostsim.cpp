@@ -299,7 +299,46 @@ static void multi_one(int form, int with_final_exp, const uint64_t* g1, const ui
   if (flag) *flag = fl;
 }
 
+// the LDS forms of the device kernels (pairing.hip.h miller_ate_lds, miller_ref_opt_generic_lds) over a plain buffer: one "lane"
+template <int K>
+static void multi_one_lds(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flag) {
+  LdsQuad mem[4 * miller_lds_slots(K)];
+  const LaneLds<1> lds = lane_lds<1>(mem, 0);
+  uint8_t fl = 0;
+  Fp12R f = with_final_exp ? miller_ate_lds<K, true>(g1, g2, form, lds, fl) : miller_ate_lds<K, false>(g1, g2, form, lds, fl);
+  if (with_final_exp) f = final_exponentiation(f);
+  fp12_store(out, f, form);
+  if (flag) *flag = fl;
+}
+
 extern "C" {
+
+int hostsim_multi_miller_lds(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, size_t k,
+                             uint64_t* out, uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t* a = g1 + 12 * k * i; const uint64_t* b = g2 + 24 * k * i;
+    uint8_t* fl = flags ? flags + i : nullptr;
+    switch (k) {
+      case 2: multi_one_lds<2>(form, with_final_exp, a, b, out + 72 * i, fl); break;
+      case 3: multi_one_lds<3>(form, with_final_exp, a, b, out + 72 * i, fl); break;
+      default: return 1;
+    }
+  }
+  return 0;
+}
+
+int hostsim_miller_ref_opt_lds(int form, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    LdsQuad mem[ref_opt_lds_bytes_per_lane() / sizeof(LdsQuad)];
+    const LaneLds<1> lds = lane_lds<1>(mem, 0);
+    const G1Jac p = g1_jac_load(g1 + 18 * i, form);
+    uint8_t fl = 0;
+    const Fp12R f = miller_ref_opt_generic_lds(p, g2 + 36 * i, form, lds, fl);
+    fp12_store(out + 72 * i, f, form);
+    if (flags) flags[i] = fl;
+  }
+  return 0;
+}
 
 int hostsim_multi_miller(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, size_t k,
                          uint64_t* out, uint8_t* flags, size_t n) {

@@ -131,6 +131,38 @@ def test_mode_a_golden_both_variants(hostsim):
         assert list(fl) == [c["flags"] for c in cases]
 
 
+def test_mode_a_lds_form_golden(hostsim):
+    """miller_ref_opt_generic_lds -- what k_miller_ref_opt_wide runs: one Fq12 accumulator in registers, the other in the slot store,
+    squaring formula, Fp2-scalar line multiplication, R + R by the doubling formulas -- on the golden cases (infinity, garbage and
+    all-zero inputs included), with bound checks."""
+    cases = load_golden("mode_a.json")["cases"]
+    g1 = enc_fps([v for c in cases for v in hx(c["g1_jac"])])
+    g2 = enc_fps([v for c in cases for v in hx(c["g2_jac"])])
+    out, fl = hostsim.miller_ref_opt_lds(g1, g2)
+    assert dec_fp12s(out) == [_fp12(c["out"]) for c in cases]
+    assert list(fl) == [c["flags"] for c in cases]
+
+
+def test_multi_pair_lds_form_against_the_oracle(hostsim):
+    """miller_ate_lds -- what k_multi_miller<2|3> run: the idle pairs' R in the slot store, changing places with the current pair's
+    after every step -- against the C oracle: Miller products (Alg. 26/27 steps) and full pairing products (homogeneous steps),
+    with a pair at infinity in every position."""
+    from blsutil import COracle, synthetic_batch
+    orc = COracle()
+    for k in (2, 3):
+        n = 6
+        g1, g2 = synthetic_batch(n, seed=700 + k, jacobian=False, k=k, pool=n)
+        g1 = g1.copy(); g2 = g2.copy()
+        for j in range(k):                                   # element j: pair j at infinity (G1 side, then G2 side on the last element)
+            g1.reshape(n, k, 12)[j, j] = 0
+        g2.reshape(n, k, 24)[n - 1, k - 1] = 0
+        for fe in (False, True):
+            exp, efl = orc.multi(g1, g2, k, final_exp=fe, threads=4)
+            out, fl = hostsim.multi_miller_lds(g1, g2, k, final_exp=fe)
+            assert np.array_equal(out, exp) and np.array_equal(fl, efl), (k, fe)
+            assert fl[:k].all() and fl[n - 1]
+
+
 def test_line_function_three_branches(hostsim):
     cases = load_golden("line_fn.json")["cases"]
     assert sorted(c["branch"] for c in cases) == ["A", "T", "V"]
