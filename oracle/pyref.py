@@ -651,6 +651,33 @@ def optimized_miller_loop(Pt, Q, generic_fp12=True, trace=None):
     return f, flags
 
 
+def optimized_miller_loop_strength_reduced(Pt, Q):
+    """The same function with the three strength reductions the device kernel applies to the reference's generic `*` / `+`
+    (none can change a field value): `f * f` by the Fq12 squaring formula, `f * embed(v)` as six Fp2 products,
+    `R + R` straight to the doubling formulas.  Used to check value equality with optimized_miller_loop and to count the Fp
+    multiplications the kernel's formulation needs (`python oracle/pyref.py`)."""
+    def scale(f, v):
+        (a0, a1, a2), (b0, b1, b2) = f
+        return ((fp2_mul(a0, v), fp2_mul(a1, v), fp2_mul(a2, v)), (fp2_mul(b0, v), fp2_mul(b1, v), fp2_mul(b2, v)))
+    R = Q
+    f_num, f_den = FP12_ONE, FP12_ONE
+    for v in PSEUDO_BINARY_ENCODING:
+        n, d, _ = optimized_line_function(R, R, Pt)
+        f_num = scale(fp12_sqr(f_num), n)
+        f_den = scale(fp12_sqr(f_den), d)
+        R = jac_double(_F2, R)
+        if v == 1:
+            n, d, _ = optimized_line_function(R, Q, Pt)
+            f_num = scale(f_num, n)
+            f_den = scale(f_den, d)
+            R = jac_add(_F2, R, Q)
+    di = fp12_inv(f_den)
+    if di is None:
+        return FP12_ZERO, FLAG_DEN_ZERO
+    f = fp12_mul(f_num, di)
+    return fp12_mul(f, f), 0
+
+
 # ======================================================================= MODE B
 # src/miller_loop_native.rs (+ src/fields_as_trees/miller_loop.rs for the final exponentiation)
 
@@ -1099,6 +1126,10 @@ if __name__ == "__main__":
     OPS.reset()
     e = final_exponentiation(ml)
     f_ops = OPS.snapshot()
+    OPS.reset()
+    out2, fl2 = optimized_miller_loop_strength_reduced((G1_GEN[0], G1_GEN[1], 1), (G2_GEN[0], G2_GEN[1], FP2_ONE))
+    a2_ops = OPS.snapshot()
+    assert out2 == out and fl2 == fl
     # the k = 3 product (BASELINE config 4): three pairs through one shared loop, then ONE final exponentiation
     OPS.reset()
     g1s = [g1_mul(k) for k in (1, 2, 3)]
@@ -1106,4 +1137,5 @@ if __name__ == "__main__":
     OPS.reset()
     ml3 = multi_miller_loop(list(zip(g1s, g2s)))
     m3_ops = OPS.snapshot()
-    print(json.dumps({"modeA_generic": a_ops, "modeB_miller": m_ops, "modeB_finalexp": f_ops, "modeB_miller_k3": m3_ops}))
+    print(json.dumps({"modeA_generic": a_ops, "modeB_miller": m_ops, "modeB_finalexp": f_ops, "modeB_miller_k3": m3_ops,
+                      "modeA_strength_reduced": a2_ops}))

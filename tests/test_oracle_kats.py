@@ -196,3 +196,20 @@ def test_hard_part_exponent_identity_of_the_staged_final_exponentiation():
     x = -O.BLS_X
     assert (O.P ** 4 - O.P ** 2 + 1) % O.R_ORDER == 0
     assert (x - 1) ** 2 * (x + O.P) * (x * x + O.P * O.P - 1) + 3 == 3 * (O.P ** 4 - O.P ** 2 + 1) // O.R_ORDER
+
+
+def test_mode_a_strength_reductions_keep_the_value():
+    """What the device kernel computes for optimized_miller_loop -- `f * f` by the squaring formula, the embedded line value as an
+    Fp2 scalar, `R + R` by the doubling formulas -- is the same Fq12 value as the literal restatement, on
+    general-Z points, on garbage coordinates and with P or Q at infinity."""
+    import random
+    from blsutil import random_pairs
+    rng = random.Random(31)
+    cases = [(P, Q) for P, Q in random_pairs(3, 77, jacobian=True)]
+    cases.append(((rng.randrange(O.P), rng.randrange(O.P), rng.randrange(O.P)),
+                  tuple((rng.randrange(O.P), rng.randrange(O.P)) for _ in range(3))))          # not on any curve
+    P0, Q0 = cases[0]
+    cases.append(((P0[0], P0[1], 0), Q0))
+    cases.append((P0, (Q0[0], Q0[1], (0, 0))))
+    for P, Q in cases:
+        assert O.optimized_miller_loop_strength_reduced(P, Q) == O.optimized_miller_loop(P, Q)
