@@ -151,8 +151,14 @@ float bls381_last_kernel_ms(const bls381_ctx* ctx);
  * final exponentiation (phase 1); < 0 when the most recent call was not a pairing / pairing-product call. */
 float bls381_last_phase_ms(const bls381_ctx* ctx, int phase);
 
-/* Mode A: optimized_miller_loop over a batch (src/miller_loop_native_optimized.rs:81).
- * g1_jac: n x 3 x 6 u64, g2_jac: n x 3 x 2 x 6, out_fq12: n x 12 x 6, flags: n bytes or NULL. */
+/* Mode A: optimized_miller_loop over a batch (src/miller_loop_native_optimized.rs:81) -- the same Fq12 value bit for bit, quirks
+ * included (LSB-first walk, numerator / denominator pair, Jacobian coordinates read as homogeneous, one final squaring; any
+ * coordinate values, on a curve or not).  The accumulators are full Fq12 values; where the reference spells a generic `*` or `+`
+ * whose operands have structure -- `f * f`, `f * Fq12::new(Fq6::new(v, 0, 0), 0)`, `R + R` -- the kernel runs the squaring formula,
+ * six Fp2 products, the doubling formulas (same field element in each case).  BLS381_OPT_REF_OPT_FP2_SHORTCUT = 1 keeps the
+ * accumulators in Fp2, where they provably live.
+ * g1_jac: n x 3 x 6 u64, g2_jac: n x 3 x 2 x 6, out_fq12: n x 12 x 6, flags: n bytes or NULL (bit BLS381_FLAG_DEN_ZERO: the
+ * reference would panic at :102, output zeroed). */
 int bls381_miller_ref_opt_batch(bls381_ctx* ctx, const uint64_t* g1_jac, const uint64_t* g2_jac,
                                 uint64_t* out_fq12, uint8_t* flags, size_t n);
 int bls381_miller_ref_opt_batch_dev(bls381_ctx* ctx, const uint64_t* g1_jac, const uint64_t* g2_jac,
