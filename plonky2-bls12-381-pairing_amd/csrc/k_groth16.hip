@@ -99,7 +99,7 @@ k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ 
       }
       ++idx;
     }
-    if (!last) f = sqr(f);
+    if (!last) f = miller_sqr<HOM>(f);
   }
   fp12_store(out + 72 * i, fit<1, 2>(conj(f)), form);
   if (flags && lane_part() == 0) flags[i] = fl;

@@ -431,6 +431,19 @@ BLS_HD_NOINLINE Fp12R ell_call(const Fp12R& f, const LineCoeffs& l, const G1Aff&
 // (doubling, addition) steps of an iteration with a uniform `pass` loop, so the instruction stream holds ONE copy of
 // each step and of the sparse multiplication -- the loop body is the whole hot path and stays I-cache friendly.
 // HOM = true walks the same schedule with the homogeneous-projective steps above (full pairings only).
+// The squaring of an iteration.  A loop whose value goes through the final exponentiation (HOM) may carry factors from Fp, so it
+// COULD square with 2 f^2 by SQR3 over Fp4 (tower.hip.h sqr_twice: 6 468 instead of 7 056 multiply-adds per lane) -- measured in round 3
+// (BLS_HOM_SQR3=1): 588 fewer multiply-adds, 852 more other instructions, 32.4 vs 31.5 ms per 2^18 loops.  Off; Miller-only results
+// need the exact square in any case.
+#ifndef BLS_HOM_SQR3
+#define BLS_HOM_SQR3 0
+#endif
+template <bool HOM>
+BLS_HD Fp12R miller_sqr(const Fp12R& f) {
+  if constexpr (HOM && BLS_HOM_SQR3) return sqr_twice(f);
+  else return sqr(f);
+}
+
 template <int N_PAIRS, bool HOM = false>
 BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
   G2Jac r[N_PAIRS];
@@ -459,7 +472,7 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
         }
       }
     }
-    if (!last) f = (N_PAIRS <= BLS_INLINE_PAIRS_MAX) ? sqr(f) : sqr_call(f);   // :106
+    if (!last) f = (N_PAIRS <= BLS_INLINE_PAIRS_MAX) ? miller_sqr<HOM>(f) : sqr_call(f);   // :106
   }
   return fit<1, 2>(conj(f));                                              // :111-113 (x < 0)
 }
@@ -616,7 +629,7 @@ BLS_HD Fp12R miller_ate_lds(const uint64_t* g1e, const uint64_t* g2e, int form, 
         phase_fence();
       }
     }
-    if (!last) f = sqr(f);
+    if (!last) f = miller_sqr<HOM>(f);
   }
   return fit<1, 2>(conj(f));
 }

@@ -323,13 +323,58 @@ template <class A, class B> struct Pair2 { A a; B b; };
 template <class A, class B> BLS_HD Pair2<A, B> pair2(const A& a, const B& b) { return Pair2<A, B>{a, b}; }
 
 // (a + b s)^2 in Fp4 = Fp2[s]/(s^2 - xi)   -- miller_loop.rs:29-44
-template <int L, int V>
-BLS_HD auto fp4_square(const Fp2<L, V>& a, const Fp2<L, V>& b) {
+template <int La, int Va, int Lb, int Vb>
+BLS_HD auto fp4_square(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
   const Fp2R t0 = sqr(a), t1 = sqr(b);
   const auto c0 = add(mul_xi(t1), t0);
   const Fp2R t2 = sqr(add(a, b));
   const auto c1 = sub(sub(t2, t0), t1);
   return pair2(c0, c1);
+}
+
+// (x0 + x1 s)(y0 + y1 s) in Fp4, Karatsuba: three Fp2 products
+template <class X0, class X1, class Y0, class Y1>
+BLS_HD auto fp4_mul(const X0& x0, const X1& x1, const Y0& y0, const Y1& y1) {
+  const Fp2R v0 = mul(x0, y0), v1 = mul(x1, y1);
+  const auto c0 = add(mul_xi(v1), v0);
+  const Fp2R m = mul(add(x0, x1), add(y0, y1));
+  const auto c1 = sub(sub(m, v0), v1);
+  return pair2(c0, c1);
+}
+
+// TWICE the square, 2 f^2, by the Chung-Hasan SQR3 formula over Fp4: with s = w^3 (s^2 = xi) and t = w (t^3 = s),
+//   f = A + B t + C t^2,   A = g0 + g3 s,  B = g1 + g4 s,  C = g2 + g5 s      (g_i = coefficient of w^i: c0 = (g0, g2, g4), c1 = (g1, g3, g5))
+//   S0 = A^2,  S1 = (A + B + C)^2,  S2 = (A - B + C)^2,  S3 = B C,  S4 = C^2
+//   2 f^2 = (2 S0 + 4 s S3) + (S1 - S2 - 4 S3 + 2 s S4) t + (S1 + S2 - 2 S0 - 2 S4) t^2
+// Four Fp4 squarings (three Fp2 squarings each) and one Fp4 product (three Fp2 products): 12 x 392 + 3 x 588 = 6 468 multiply-adds per
+// lane against 12 x 588 = 7 056 for the complex squaring over two Karatsuba Fq6 products.  The factor 2 (SQR3's interpolation
+// halves S1 + S2) is an element of Fp: a Miller value that goes through the final exponentiation may carry it, an exact square
+// may not.  Measured against sqr() in the homogeneous-step Miller loop (pairing.hip.h BLS_HOM_SQR3): fewer multiply-adds, more
+// additions and carry passes, 3 % slower -- kept as a checked routine (tests/test_hostsim.py) and an A/B switch, not used by default.
+template <int L, int V>
+BLS_HD Fp12R sqr_twice(const Fp12<L, V>& f) {
+  const auto& g0 = f.c0.c0; const auto& g2 = f.c0.c1; const auto& g4 = f.c0.c2;
+  const auto& g1 = f.c1.c0; const auto& g3 = f.c1.c1; const auto& g5 = f.c1.c2;
+  const auto S0 = fp4_square(g0, g3);
+  const auto S4 = fp4_square(g2, g5);
+  const auto ac0 = add(g0, g2);                                            // A + C
+  const auto ac1 = add(g3, g5);
+  const auto S1 = fp4_square(add(ac0, g1), add(ac1, g4));
+  const auto S2 = fp4_square(sub(ac0, g1), sub(ac1, g4));
+  const auto S3 = fp4_mul(g1, g4, g2, g5);
+  // (add / sub / dbl condition their operands by themselves when a bound would leave the representable range, fp.hip.h)
+  const auto s3a4 = dbl(dbl(S3.a));                                        // 4 S3
+  const auto s3b4 = dbl(dbl(S3.b));
+  // coefficient of 1:   2 S0 + 4 s S3 = (2 S0.a + 4 xi S3.b) + (2 S0.b + 4 S3.a) s
+  const auto h0 = add(dbl(S0.a), mul_xi(s3b4));
+  const auto h3 = add(dbl(S0.b), s3a4);
+  // coefficient of t:   S1 - S2 - 4 S3 + 2 s S4 = (S1.a - S2.a - 4 S3.a + 2 xi S4.b) + (S1.b - S2.b - 4 S3.b + 2 S4.a) s
+  const auto h1 = add(sub(sub(S1.a, S2.a), s3a4), mul_xi(dbl(S4.b)));
+  const auto h4 = add(sub(sub(S1.b, S2.b), s3b4), dbl(S4.a));
+  // coefficient of t^2: S1 + S2 - 2 S0 - 2 S4
+  const auto h2 = sub(sub(add(S1.a, S2.a), dbl(S0.a)), dbl(S4.a));
+  const auto h5 = sub(sub(add(S1.b, S2.b), dbl(S0.b)), dbl(S4.b));
+  return Fp12R(Fp6R(fit<1, 2>(h0), fit<1, 2>(h2), fit<1, 2>(h4)), Fp6R(fit<1, 2>(h1), fit<1, 2>(h3), fit<1, 2>(h5)));
 }
 
 // Granger-Scott squaring   -- miller_loop.rs:46-104

@@ -199,6 +199,7 @@ int hostsim_fp12_op(int op, int form, const uint64_t* a, const uint64_t* b, uint
       // kernels compile (lazy sums, BLS_LAZY_014), 11 = Karatsuba as the reference writes it (fq12_target_tree.rs:157-176)
       case 10: r = mul_by_014_lazy(x, y.c0.c0, y.c0.c1, y.c1.c1); break;
       case 11: r = mul_by_014(x, y.c0.c0, y.c0.c1, y.c1.c1); break;
+      case 13: r = sqr_twice(x); break;                                   // 2 x^2 (Chung-Hasan SQR3 over Fp4)
       default: return 1;
     }
     fp12_store(out + 72 * i, r, form);

@@ -85,6 +85,20 @@ def test_mul_by_014_lazy_sums_and_karatsuba(hostsim):
     assert dec_fp12s(hostsim.fp12_op(11, X, Y)) == exp
 
 
+def test_twice_square_sqr3_over_fp4(hostsim):
+    """sqr_twice (tower.hip.h): 2 f^2 by the Chung-Hasan SQR3 formula over Fp4 (the A/B alternative for the squaring of the
+    homogeneous-step Miller loops, BLS_HOM_SQR3) against the big-integer tower: random elements, a sparse one (a line value),
+    zero, one and all-(p-1)."""
+    rng = random.Random(3303)
+    xs = [rand_fp12(rng) for _ in range(40)]
+    xs += [O.FP12_ONE, O.fp12_unflatten([0] * 12), O.fp12_unflatten([O.P - 1] * 12)]
+    line = [[rand_fp2(rng), rand_fp2(rng), (0, 0)], [(0, 0), rand_fp2(rng), (0, 0)]]
+    xs.append(tuple(tuple(c) for c in line))
+    got = dec_fp12s(hostsim.fp12_op(13, enc_fp12s(xs)))
+    for x, g in zip(xs, got):
+        assert g == O.fp12_mul(O.fp12_sqr(x), O.fp12_from_fp2((2, 0)))
+
+
 def test_final_exp_split_with_batched_inversion(hostsim):
     """The three-kernel form of the final exponentiation (norms -> simultaneous inversion in chunks of eight -> finish)
     gives the oracle's bits for every element, whatever the chunk alignment; zero elements stay zero and do not disturb
