@@ -465,6 +465,12 @@ def test_fexp_auto_both_sides_of_the_switch(engine, coracle, pools, n):
     o = out.reshape(2, n // 2, 72)
     assert np.array_equal(o[0], o[1]) and not fl.any()
     assert _oracle_sample(coracle, g1, g2, out, n, 512)
+    # the library's own record of what it ran (BLS381_INFO_*: bench.py builds its kernel labels from these)
+    assert engine.get_option(B.INFO_LAST_FEXP_MODE) == (B.FEXP_STAGED if n >= (1 << 10) else B.FEXP_BATCHED_INVERSION)
+    assert engine.get_option(B.INFO_LAST_FEXP_PIPELINES) == (2 if n >= (1 << 18) else 1)
+    assert engine.get_option(B.INFO_LAST_MILLER_HOMOGENEOUS) == 1 and engine.get_option(B.INFO_LAST_MILLER_GROUP) == 1
+    engine.multi_miller_loop(g1[: 12 * 64], g2[: 24 * 64], 1)
+    assert engine.get_option(B.INFO_LAST_FEXP_MODE) == -1 and engine.get_option(B.INFO_LAST_MILLER_HOMOGENEOUS) == 0
 
 
 def test_miller_only_64k_generic_mode_a_and_mode_b(engine, coracle, pools):
