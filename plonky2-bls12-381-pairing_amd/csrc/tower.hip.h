@@ -350,7 +350,7 @@ BLS_HD auto fp4_mul(const X0& x0, const X1& x1, const Y0& y0, const Y1& y1) {
 // lane against 12 x 588 = 7 056 for the complex squaring over two Karatsuba Fq6 products.  The factor 2 (SQR3's interpolation
 // halves S1 + S2) is an element of Fp: a Miller value that goes through the final exponentiation may carry it, an exact square
 // may not.  Measured against sqr() in the homogeneous-step Miller loop (pairing.hip.h BLS_HOM_SQR3): fewer multiply-adds, more
-// additions and carry passes, 3 % slower -- kept as a checked routine (tests/test_hostsim.py) and an A/B switch, not used by default.
+// additions and carry passes, 3 % slower -- kept as a checked routine (host build: tests/hostsim) and an A/B switch, not used by default.
 template <int L, int V>
 BLS_HD Fp12R sqr_twice(const Fp12<L, V>& f) {
   const auto& g0 = f.c0.c0; const auto& g2 = f.c0.c1; const auto& g4 = f.c0.c2;
