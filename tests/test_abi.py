@@ -83,3 +83,14 @@ def test_fq12_order_helpers_host_only():
     assert np.array_equal(my, enc_fps([c for x in xs for c in O.fp12_to_myfq12(x)]))
     lib.bls381_fq12_myfq12_to_ark(my.ctypes.data_as(u64p), back.ctypes.data_as(u64p), len(xs))
     assert np.array_equal(back, ark)
+
+
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md shows the reference-side (Rust `extern "C"`) binding of EVERY function include/bls381_hip.h declares."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "bls381_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"^(?:int|void|float|const char\*|bls381_ctx\*)\s+(bls381_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 50
+    bound = set(re.findall(r"fn (bls381_[a-z0-9_]+)\s*\(", doc))
+    assert declared - bound == set(), sorted(declared - bound)
