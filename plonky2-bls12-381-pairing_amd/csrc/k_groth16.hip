@@ -35,7 +35,6 @@ template <int NVAR, int NFIXED, bool HOM>
 __global__ void __launch_bounds__(G16_BLOCK)
 k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ g2_var, const uint64_t* __restrict__ prepared,
                   uint64_t* __restrict__ out, uint8_t* __restrict__ flags, size_t n, int form) {
-  constexpr int G16_FIXED = NFIXED;
   constexpr int G16_N_FP = NFIXED * G16_FP_PER_POINT;
   constexpr int NP = NVAR + NFIXED;
   __shared__ __attribute__((aligned(16))) uint32_t coef[G16_N_FP * G16_FP_STRIDE];
@@ -79,29 +78,8 @@ k_prepared_miller(const uint64_t* __restrict__ g1, const uint64_t* __restrict__ 
     return l;
   };
 
-  G2Jac r;
-  if constexpr (NVAR == 1) { r.x = q0.x; r.y = q0.y; r.z = Fp2R(fp2_one()); }
-  Fp12R f = fp12_one();
-  int idx = 0;
-  for (int b = 61; b >= -1; --b) {             // same schedule as miller_ate (pairing.hip.h)
-    const bool last = b < 0;
-    const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
-    for (int pass = 0; pass < passes; ++pass) {
-      if constexpr (NVAR == 1) {
-        const LineCoeffs l0 = HOM ? ((pass == 0) ? doubling_step_hom(r) : addition_step_hom(r, q0))
-                                  : ((pass == 0) ? doubling_step(r) : addition_step(r, q0));
-        if (!skip[0]) f = ell(f, l0, p[0]);
-      }
-#pragma unroll
-      for (int j = 0; j < G16_FIXED; ++j) {    // coefficients come from LDS: no curve arithmetic for the fixed points
-        const LineCoeffs lj = fixed_line(j, idx);
-        if (!skip[NVAR + j]) f = ell(f, lj, p[NVAR + j]);
-      }
-      ++idx;
-    }
-    if (!last) f = miller_sqr<HOM>(f);
-  }
-  fp12_store(out + 72 * i, fit<1, 2>(conj(f)), form);
+  const Fp12R f = miller_prepared<NVAR, NFIXED, HOM>(p, q0, skip, fixed_line);      // pairing.hip.h: the loop itself
+  fp12_store(out + 72 * i, f, form);
   if (flags && lane_part() == 0) flags[i] = fl;
 }
 

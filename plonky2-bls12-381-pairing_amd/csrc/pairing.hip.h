@@ -477,6 +477,38 @@ BLS_HD Fp12R miller_ate(const G1Aff* p, const G2Aff* q, const bool* skip) {
   return fit<1, 2>(conj(f));                                              // :111-113 (x < 0)
 }
 
+// Pairing products with FIXED (prepared) G2 points: NVAR in {0, 1} pairs walk their own curve steps, NFIXED pairs take their line
+// coefficients from `fixed_line(j, idx)` -- triple `idx` (0..67, loop order) of fixed point j, e.g. out of LDS (k_groth16.hip) or out of
+// a plain array (tests/hostsim).  p[0..NVAR) belong to the variable pair, p[NVAR..) to the fixed ones; same schedule as miller_ate.
+// HOM: homogeneous steps for the variable pair (its lines then differ from Alg. 26/27's by Fp2 factors the final exponentiation
+// kills; the prepared lines are Alg. 26/27's either way).
+template <int NVAR, int NFIXED, bool HOM, class FixedLine>
+BLS_HD Fp12R miller_prepared(const G1Aff* p, const G2Aff& q0, const bool* skip, FixedLine fixed_line) {
+  G2Jac r;
+  if constexpr (NVAR == 1) { r.x = q0.x; r.y = q0.y; r.z = Fp2R(fp2_one()); }
+  Fp12R f = fp12_one();
+  int idx = 0;
+  for (int b = 61; b >= -1; --b) {
+    const bool last = b < 0;
+    const int passes = (!last && (((BLS_X_PARAM >> 1) >> (b < 0 ? 0 : b)) & 1ull)) ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      if constexpr (NVAR == 1) {
+        const LineCoeffs l0 = HOM ? ((pass == 0) ? doubling_step_hom(r) : addition_step_hom(r, q0))
+                                  : ((pass == 0) ? doubling_step(r) : addition_step(r, q0));
+        if (!skip[0]) f = ell(f, l0, p[0]);
+      }
+#pragma unroll
+      for (int j = 0; j < NFIXED; ++j) {       // no curve arithmetic for the fixed points
+        const LineCoeffs lj = fixed_line(j, idx);
+        if (!skip[NVAR + j]) f = ell(f, lj, p[NVAR + j]);
+      }
+      ++idx;
+    }
+    if (!last) f = sqr(f);
+  }
+  return fit<1, 2>(conj(f));
+}
+
 // G2Prepared: the 68 line-coefficient triples of one G2 point in loop order (63 doubling + 5 addition steps),
 // the precomputation behind `G2PreparedTarget::from` (src/miller_loop_target.rs:23-76; `assert_eq!(coeffs.len(), 68)`
 // at :69).  `emit(index, coeffs)` receives each triple (a, b, c) = (tmp0, tmp3, tmp6) / (t10, t1, t9).

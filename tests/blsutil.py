@@ -184,6 +184,16 @@ class HostSim:
         assert rc == 0
         return out, flags
 
+    def prepared_pairing(self, g1, g2_var, prepared, n_var, n_fixed, hom=True, form=IO_ARK_MONT):
+        """k_prepared_miller's loop (pairing.hip.h miller_prepared) + final exponentiation; buffers as bls381_prepared_pairing_batch"""
+        n = len(g1) // (12 * (n_var + n_fixed))
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        rc = self.lib.hostsim_prepared_pairing(form, n_var, n_fixed, int(hom), _ptr(g1), _ptr(g2_var) if n_var else None, _ptr(prepared),
+                                               _ptr(out), _ptr(flags, ctypes.c_uint8), ctypes.c_size_t(n))
+        assert rc == 0
+        return out, flags
+
     def multi_miller_lds(self, g1, g2, k, final_exp=False, form=IO_ARK_MONT):
         """products of k = 2, 3 pairs as k_multi_miller<2|3> runs them: the idle pairs' R in the slot store (miller_ate_lds)"""
         n = len(g1) // (12 * k)

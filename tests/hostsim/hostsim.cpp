@@ -300,6 +300,27 @@ static void multi_one(int form, int with_final_exp, const uint64_t* g1, const ui
   if (flag) *flag = fl;
 }
 
+// k_prepared_miller's loop (pairing.hip.h miller_prepared) with the prepared coefficients in a plain array; always followed by
+// the final exponentiation.  prepared: nfixed x 68 x 3 x 2 Fp in ABI form (bls381_g2_prepare_batch layout).
+template <int NVAR, int NFIXED>
+static void prepared_one(int form, int hom, const uint64_t* g1, const uint64_t* g2v, const FpR* coef, uint64_t* out, uint8_t* flag) {
+  constexpr int NP = NVAR + NFIXED;
+  G1Aff p[NP]; bool skip[NP]; uint8_t fl = 0;
+  for (int j = 0; j < NP; ++j) { bool inf; p[j] = g1_aff_load(g1 + 12 * j, form, inf); skip[j] = inf; }
+  G2Aff q0{};
+  if (NVAR == 1) { bool qinf; q0 = g2_aff_load(g2v, form, qinf); skip[0] = skip[0] || qinf; }
+  for (int j = 0; j < NP; ++j) if (skip[j]) fl |= FLAG_INFINITY;
+  auto fixed_line = [&](int j, int idx) {
+    const FpR* b = coef + (size_t)((j * 68 + idx) * 3) * 2;
+    LineCoeffs l;
+    l.a = Fp2R(b[0], b[1]); l.b = Fp2R(b[2], b[3]); l.c = Fp2R(b[4], b[5]);
+    return l;
+  };
+  Fp12R f = hom ? miller_prepared<NVAR, NFIXED, true>(p, q0, skip, fixed_line) : miller_prepared<NVAR, NFIXED, false>(p, q0, skip, fixed_line);
+  fp12_store(out, final_exponentiation(f), form);
+  if (flag) *flag = fl;
+}
+
 // the LDS forms of the device kernels (pairing.hip.h miller_ate_lds, miller_ref_opt_generic_lds) over a plain buffer: one "lane"
 template <int K>
 static void multi_one_lds(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flag) {
@@ -313,6 +334,25 @@ static void multi_one_lds(int form, int with_final_exp, const uint64_t* g1, cons
 }
 
 extern "C" {
+
+int hostsim_prepared_pairing(int form, int nvar, int nfixed, int hom, const uint64_t* g1, const uint64_t* g2v, const uint64_t* prepared,
+                             uint64_t* out, uint8_t* flags, size_t n) {
+  const size_t ncoef = (size_t)nfixed * 68 * 3 * 2;
+  FpR* coef = new FpR[ncoef];
+  for (size_t t = 0; t < ncoef; ++t) coef[t] = fp_load(prepared + 6 * t, form);
+  int rc = 0;
+  for (size_t i = 0; i < n && rc == 0; ++i) {
+    const uint64_t* a = g1 + 12 * (size_t)(nvar + nfixed) * i; const uint64_t* b = nvar ? g2v + 24 * i : nullptr;
+    uint8_t* fl = flags ? flags + i : nullptr;
+    if (nvar == 1 && nfixed == 2) prepared_one<1, 2>(form, hom, a, b, coef, out + 72 * i, fl);
+    else if (nvar == 1 && nfixed == 1) prepared_one<1, 1>(form, hom, a, b, coef, out + 72 * i, fl);
+    else if (nvar == 0 && nfixed == 1) prepared_one<0, 1>(form, hom, a, b, coef, out + 72 * i, fl);
+    else if (nvar == 0 && nfixed == 2) prepared_one<0, 2>(form, hom, a, b, coef, out + 72 * i, fl);
+    else rc = 1;
+  }
+  delete[] coef;
+  return rc;
+}
 
 int hostsim_multi_miller_lds(int form, int with_final_exp, const uint64_t* g1, const uint64_t* g2, size_t k,
                              uint64_t* out, uint8_t* flags, size_t n) {

@@ -177,6 +177,30 @@ def test_multi_pair_lds_form_against_the_oracle(hostsim):
             assert fl[:k].all() and fl[n - 1]
 
 
+def test_prepared_pairing_loop_against_the_oracle(hostsim):
+    """miller_prepared (pairing.hip.h) -- the loop of k_prepared_miller: the variable pair walks its curve steps, the fixed pairs take
+    G2Prepared coefficients (here from a plain array, on the device from LDS) -- for the Groth16 shape (1, 2) and the shapes
+    (1, 1), (0, 1), (0, 2), homogeneous and Alg. 26/27 steps, against the generic product of the C oracle; a G1 point at infinity
+    in a fixed slot and the variable G2 point at infinity included."""
+    from blsutil import COracle, synthetic_batch
+    orc = COracle()
+    n = 4
+    g1, g2 = synthetic_batch(n, seed=4100, jacobian=False, k=3, pool=n)
+    g1 = g1.copy().reshape(n, 3, 12); g2 = g2.copy().reshape(n, 3, 24)
+    g2[:, 1] = g2[0, 1]; g2[:, 2] = g2[0, 2]                       # pairs 1 and 2: the same G2 points on every element
+    g1[1, 2] = 0                                                    # P at infinity in a fixed slot
+    g2[2, 0] = 0                                                    # the variable Q at infinity
+    prep = hostsim.g2_prepare(np.ascontiguousarray(g2[0, 1:3]).reshape(-1))
+    for n_var, n_fixed in ((1, 2), (1, 1), (0, 1), (0, 2)):
+        cols = list(range(0 if n_var else 1, 1 + n_fixed))         # which of the three pairs take part
+        a = np.ascontiguousarray(g1[:, cols]).reshape(-1); b = np.ascontiguousarray(g2[:, cols]).reshape(-1)
+        exp, efl = orc.multi(a, b, len(cols), final_exp=True, threads=4)
+        pc = prep[: n_fixed * 68 * 36]
+        for hom in (True, False):
+            out, fl = hostsim.prepared_pairing(a, np.ascontiguousarray(g2[:, 0]).reshape(-1), pc, n_var, n_fixed, hom=hom)
+            assert np.array_equal(out, exp) and np.array_equal(fl, efl), (n_var, n_fixed, hom)
+
+
 def test_line_function_three_branches(hostsim):
     cases = load_golden("line_fn.json")["cases"]
     assert sorted(c["branch"] for c in cases) == ["A", "T", "V"]
