@@ -301,6 +301,10 @@ int bls381_multi_miller_batch_sharded(bls381_multi* m, const uint64_t* g1_aff, c
 /* optimized_miller_loop (src/miller_loop_native_optimized.rs:81); same buffers as bls381_miller_ref_opt_batch */
 int bls381_miller_ref_opt_batch_sharded(bls381_multi* m, const uint64_t* g1_jac, const uint64_t* g2_jac,
                                         uint64_t* out_fq12, uint8_t* flags, size_t n);
+/* the Groth16-verify shape with its two fixed G2 points prepared (BASELINE config 4 for a single-process caller): same buffers as
+ * bls381_groth16_pairing_batch; every device stages the 2 x 68 coefficient triples (src/miller_loop_target.rs:23-76) itself */
+int bls381_groth16_pairing_batch_sharded(bls381_multi* m, const uint64_t* g1_aff, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                         uint64_t* out_gt, uint8_t* flags, size_t n);
 
 #ifdef __cplusplus
 }

@@ -933,6 +933,14 @@ int bls381_multi_miller_batch_sharded(bls381_multi* m, const uint64_t* g1, const
   });
 }
 
+int bls381_groth16_pairing_batch_sharded(bls381_multi* m, const uint64_t* g1, const uint64_t* g2_var, const uint64_t* prepared_fixed,
+                                         uint64_t* out, uint8_t* flags, size_t n) {
+  if (!m || m->ctx.empty() || (n && (!g1 || !g2_var || !prepared_fixed || !out))) return BLS381_E_INVALID;
+  return sharded(m, n, [&](bls381_ctx* c, size_t first, size_t cnt) {
+    return bls381_groth16_pairing_batch(c, g1 + 36 * first, g2_var + 24 * first, prepared_fixed, out + 72 * first, flags ? flags + first : nullptr, cnt);
+  });
+}
+
 int bls381_miller_ref_opt_batch_sharded(bls381_multi* m, const uint64_t* g1, const uint64_t* g2, uint64_t* out, uint8_t* flags, size_t n) {
   if (!m || m->ctx.empty() || (n && (!g1 || !g2 || !out))) return BLS381_E_INVALID;
   return sharded(m, n, [&](bls381_ctx* c, size_t first, size_t cnt) {

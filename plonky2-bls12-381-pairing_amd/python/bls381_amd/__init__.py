@@ -51,6 +51,7 @@ SYMBOLS = [
     "bls381_g1_op_batch", "bls381_g2_op_batch", "bls381_g1_decompress_batch", "bls381_g2_decompress_batch",
     "bls381_create_multi", "bls381_destroy_multi", "bls381_multi_device_count", "bls381_multi_context", "bls381_multi_set_option",
     "bls381_multi_pairing_batch_sharded", "bls381_multi_miller_batch_sharded", "bls381_miller_ref_opt_batch_sharded",
+    "bls381_groth16_pairing_batch_sharded",
 ]
 
 
@@ -117,6 +118,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.bls381_multi_pairing_batch_sharded.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
     lib.bls381_multi_miller_batch_sharded.argtypes = [vp, u64p, u64p, sz, u64p, u8p, sz]
     lib.bls381_miller_ref_opt_batch_sharded.argtypes = [vp, u64p, u64p, u64p, u8p, sz]
+    lib.bls381_groth16_pairing_batch_sharded.argtypes = [vp, u64p, u64p, u64p, u64p, u8p, sz]
     # device-pointer twins take raw addresses
     lib.bls381_miller_ref_opt_batch_dev.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.bls381_multi_miller_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
@@ -186,6 +188,21 @@ class MultiEngine:
 
     def optimized_miller_loop(self, g1_jac, g2_jac, out=None):
         return self._run(self.lib.bls381_miller_ref_opt_batch_sharded, "bls381_miller_ref_opt_batch_sharded", g1_jac, g2_jac, 18, 36, None, out)
+
+    def groth16_pairing(self, g1_aff, g2_var, prepared_fixed):
+        """e(P0,Q0) e(P1,Q1) e(P2,Q2) per element with Q1, Q2 fixed for the batch (Engine.g2_prepare output), sharded over the devices"""
+        a, pa = _u64(g1_aff)
+        b, pb = _u64(g2_var)
+        c, pc = _u64(prepared_fixed)
+        n = a.size // 36
+        assert a.size == n * 36 and b.size == n * 24 and c.size == 2 * 68 * 36, "ragged input"
+        out = np.zeros(n * 72, dtype=np.uint64)
+        flags = np.zeros(n, dtype=np.uint8)
+        rc = self.lib.bls381_groth16_pairing_batch_sharded(self._m, pa, pb, pc, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                           flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n)
+        if rc != 0:
+            raise Bls381Error("bls381_groth16_pairing_batch_sharded: " + self.lib.bls381_strerror(rc).decode())
+        return out, flags
 
 
 class Engine:

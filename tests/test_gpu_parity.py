@@ -548,6 +548,19 @@ def test_multi_device_context_shards_contiguous_ranges(coracle):
             assert np.array_equal(outm, expm)
         finally:
             m.close()
+    m = B.MultiEngine([0, 0, 0])
+    try:                                                   # the Groth16 shape with prepared fixed points, three uneven ranges
+        n = 1000
+        g1, g2 = synthetic_batch(n, seed=8123, jacobian=False, k=3, pool=50)
+        g2 = g2.copy().reshape(n, 3, 24); g2[:, 1] = g2[0, 1]; g2[:, 2] = g2[0, 2]
+        eng0 = B.Engine(0)
+        prep, _ = eng0.g2_prepare(np.ascontiguousarray(g2[0, 1:3]).reshape(-1))
+        exp, efl = coracle.multi(g1, g2.reshape(-1), 3, final_exp=True, threads=16)
+        out, fl = m.groth16_pairing(g1, np.ascontiguousarray(g2[:, 0]).reshape(-1), prep)
+        assert np.array_equal(out, exp) and np.array_equal(fl, efl)
+        eng0.close()
+    finally:
+        m.close()
     m = B.MultiEngine([0, 0])
     try:
         j1, j2 = synthetic_batch(301, seed=77, jacobian=True, pool=30)
