@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s
 INT_MAC_PEAK = 30.3e12                      # measured v_mad_u64_u32 lane-ops/s, profiles/r01_valu_rates_mi355x.txt
 SPOT_CHECK = 256                            # elements of rank 0's batch compared with the oracle (spread over the batch)
 SPOT_SEED = 20261005                        # seed of the sample of checked elements
+EXCHANGE_DEADLINE_S = 300                   # N > 1: the scatter / launch / gather flow after the timed region gets this long
 
 
 def baseline_metric():
@@ -220,13 +221,18 @@ def main(argv=None):
             assert full.numel() == n_units * world * 72
         del full
 
-    exchange = None
+    exchange, exchange_hung = None, False
     do_exchange = args.exchange == 1 or (args.exchange == -1 and distributed)
     if do_exchange and distributed and args.workload in ("pairing", "groth16"):
         # SURVEY 8e flow for a caller whose batch lives on rank 0: scatter inputs, launch, gather results (bls381_amd.sharding).
         # Rank 0 rebuilds the whole global batch (ranks own consecutive element ranges of it), every rank then checks the
         # scattered-and-recomputed results against what it computed from its resident shard.
-        try:
+        # The flow runs on a worker thread with a deadline: the timed region is over and its numbers are final -- a point-to-point
+        # exchange that never completes (it has not yet run on a real multi-GPU node) must cost this record, not the headline line.
+        import threading
+        box = {}
+
+        def exchange_flow():
             from bls381_amd.sharding import scatter_batch, gather_results
             host = args.backend != "nccl"                     # gloo rehearsal: point-to-point needs CPU tensors
             xdev = torch.device("cpu") if host else dev
@@ -258,13 +264,30 @@ def main(argv=None):
                 if not same:
                     raise SystemExit("bench: scattered/gathered results differ from the resident-shard results")
                 in_b, out_b = n_total * 288 * k * (world - 1) / world, n_total * 577 * (world - 1) / world
-                exchange = {"scatter_ms": (x1 - x0) * 1e3, "compute_ms": (x2 - x1) * 1e3, "gather_ms": (x3 - x2) * 1e3,
-                            "scatter_GBps": in_b / (x1 - x0) / 1e9, "gather_GBps": out_b / (x3 - x2) / 1e9,
+                return {"scatter_ms": (x1 - x0) * 1e3, "compute_ms": (x2 - x1) * 1e3, "gather_ms": (x3 - x2) * 1e3,
+                        "scatter_GBps": in_b / (x1 - x0) / 1e9, "gather_GBps": out_b / (x3 - x2) / 1e9,
                             "end_to_end_units_per_s": n_total / (x3 - x0), "staged_through_host": host,
                             "results_match_resident_shards": same}
-            del full_in, res
-        except (RuntimeError, ValueError) as e:      # an exchange that fails the same way on every rank must not cost the headline line
-            exchange = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            return None
+
+        def worker():
+            try:
+                torch.cuda.set_device(dev_index)
+                box["result"] = exchange_flow()
+            except SystemExit as e:
+                box["fatal"] = str(e)
+            except (RuntimeError, ValueError) as e:      # an exchange that fails the same way on every rank must not cost the headline line
+                box["result"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+        th.join(EXCHANGE_DEADLINE_S)
+        if th.is_alive():
+            exchange_hung = True
+            exchange = {"error": "no completion within %d s (ranks exit without tearing the process group down)" % EXCHANGE_DEADLINE_S}
+        elif "fatal" in box:
+            raise SystemExit(box["fatal"])
+        else:
+            exchange = box.get("result")
 
     # spot parity inside the bench, EVERY workload: SPOT_CHECK elements spread over rank 0's batch against the oracle (checker only,
     # after the timed region); config.parity_spot_check_cover says how many different pool points P and Q the checked elements use.
@@ -440,6 +463,9 @@ def main(argv=None):
                                               "(same algorithm; the Rust reference cannot be built here), %.1f s wall on %d threads; "
                                               "single_thread: the first %d units on one thread, %.2f s" % (sample, cdt, threads, one, cdt1)}
         print(json.dumps(line), flush=True)
+    if distributed and exchange_hung:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)                          # a collective is stuck: destroy_process_group would wait for it
     if distributed:
         dist.destroy_process_group()
 
